@@ -1,0 +1,449 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Run only in the build container (``/root/reference`` does not exist on the GPU
+box):  ``cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py``
+
+Nothing of the reference is copied: the script imports its modules from where
+they lie, feeds them seeded synthetic inputs (``ddnerf_amd/synthetic.py``) and
+stores inputs + outputs (+ captured internals) as small ``.npz`` files.
+Oracle here = reference source + torch 2.10.0 CPU.  Every random tensor the
+reference draws is reproduced by re-seeding torch and replaying the same draw,
+so the fixtures carry them explicitly.
+"""
+import importlib.util
+import os
+import sys
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+# the reference's top-level packages are called `models`, `general_utils`; make sure
+# they win over this repo's drop-in `models` alias
+sys.path = [REF] + [p for p in sys.path if os.path.abspath(p or ".") != REPO]
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("synthetic", os.path.join(REPO, "ddnerf_amd", "synthetic.py"))
+synthetic = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(synthetic)
+
+from general_utils.cfgnode import CfgNode  # noqa: E402
+from general_utils import math_utils as ref_math  # noqa: E402
+from general_utils import nerf_helpers as ref_helpers  # noqa: E402
+from general_utils import volume_rendering_utils as ref_vr  # noqa: E402
+from models import models as ref_models  # noqa: E402
+from models import samplers as ref_samplers  # noqa: E402
+from models import dd_utils as ref_dd  # noqa: E402
+
+import warnings  # noqa: E402
+
+warnings.filterwarnings("ignore")
+torch.set_num_threads(8)
+
+T = torch.from_numpy
+
+
+def npy(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def save(name, **arrs):
+    arrs = {k: npy(v) for k, v in arrs.items() if v is not None}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-40s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def load_cfg(fname, nc, nf, kind=None, **over):
+    cfg = CfgNode(yaml.load(open(os.path.join(REF, "configs", fname)), Loader=yaml.FullLoader))
+    for mode in ("train", "validation"):
+        cfg.nerf[mode]["num_coarse"] = nc
+        cfg.nerf[mode]["num_fine"] = nf
+    if kind == "real360":  # normalize_poses rescaling done by the data loader (data_utils/data_utils.py:67-74)
+        cfg.dataset.near = cfg.dataset.near / cfg.dataset.normalize_factor
+        cfg.dataset.far = cfg.dataset.far / cfg.dataset.normalize_factor
+    for k, v in over.items():
+        sec, key = k.split("__")
+        setattr(getattr(cfg, sec), key, v)
+    return cfg
+
+
+def load_weights(module, depth_head, seed, sharpen=1.0):
+    sd = synthetic.make_state_dict(depth_head, seed, sharpen)
+    module.load_state_dict({k: T(v) for k, v in sd.items()})
+
+
+CFG_OF = {"blender": "config_blender.yml", "llff": "config_ff.yml", "real360": "config_360.yml"}
+CFG_MIP_OF = {"blender": "config_blender_mipnerf.yml", "llff": "config_ff_mipnerf.yml", "real360": "config_360_mipnerf.yml"}
+
+
+# ----------------------------------------------------------------------------------------------
+# 1. first-cycle sampler (a2)
+# ----------------------------------------------------------------------------------------------
+def gen_first_cycle():
+    out = {}
+    for tag, (near, far, nc, lindisp) in {
+        "lin": (2.0, 6.0, 64, False),
+        "disp": (0.2, 2.8, 32, True),
+        "ndc": (0.0, 1.0, 16, False),
+    }.items():
+        cfg = load_cfg("config_blender.yml", nc, nc)
+        n = 19
+        nr = torch.full((n, 1), near)
+        fr = torch.full((n, 1), far)
+        for mode, perturb in (("train", True), ("validation", False)):
+            cfg.nerf[mode]["perturb"] = perturb
+            cfg.nerf[mode]["lindisp"] = lindisp
+            torch.manual_seed(7)
+            t = ref_samplers.sample_first_cycle(cfg, nr, fr, mode)
+            torch.manual_seed(7)
+            t_rand = torch.rand((n, nc + 1))
+            if not perturb:
+                t = t.expand(n, nc + 1) if t.shape[0] != n else t
+            out["%s_%s_t" % (tag, mode)] = t.contiguous()
+            out["%s_%s_rand" % (tag, mode)] = t_rand
+        out["%s_lin" % tag] = torch.linspace(0.0, 1.0, nc + 1)
+        out["%s_meta" % tag] = np.array([near, far, nc, int(lindisp)], dtype=np.float64)
+    save("first_cycle", **out)
+
+
+# ----------------------------------------------------------------------------------------------
+# 2. encode (a1, a3, a4, a5) + MLP (a7)
+# ----------------------------------------------------------------------------------------------
+def gen_encode():
+    for kind, n, s, shape in (("blender", 6, 64, "cone"), ("llff", 5, 16, "cone"), ("real360", 5, 32, "cone"),
+                              ("blender", 3, 8, "cylinder")):
+        cfg = load_cfg(CFG_OF[kind], s, s, kind)
+        cfg.nerf.ray_shape = shape
+        model = ref_models.DDNerfModel(cfg)
+        load_weights(model.coarse, True, 11)
+        load_weights(model.fine, False, 12)
+        ro, rd, rad, _ = synthetic.make_rays(kind, n, seed=3)
+        rays = model.get_rays_batches(T(ro), T(rd), T(rad), "train")[0]
+        near, far = rays[:, 7:8], rays[:, 8:9]
+        torch.manual_seed(5)
+        t_vals = ref_samplers.sample_first_cycle(cfg, near, far, "train")
+        means, covs = ref_math.cast_rays(t_vals, rays[:, :3], rays[:, 3:6], rays[:, 6:7], shape)
+        ipe = ref_math.integrated_pos_enc((means, covs))
+        dirs = model.encode_direction_fn(rays[:, -3:])
+        with torch.no_grad():
+            raw6 = model.run_network(rays, t_vals, model.coarse, "train")
+            raw4 = model.run_network(rays, t_vals, model.fine, "train")
+        save("encode_%s_%s" % (kind, shape), ro=ro, rd=rd, rad=rad, near=float(cfg.dataset.near),
+             far=float(cfg.dataset.far), rays=rays, t_vals=t_vals, means=means, covs=covs, ipe=ipe, dirs=dirs,
+             raw6=raw6, raw4=raw4, seeds=np.array([11, 12]))
+
+
+# ----------------------------------------------------------------------------------------------
+# 3. compositing (a10)
+# ----------------------------------------------------------------------------------------------
+def gen_composite():
+    rng = np.random.Generator(np.random.PCG64(21))
+    for tag, kind, n, s, white, use_mus, noise_std, scale in (
+        ("blender_mus_noise", "blender", 40, 64, False, True, 1.0, 3.0),
+        ("blender_plain", "blender", 33, 128, False, False, 0.0, 6.0),
+        ("blender_white", "blender", 17, 32, True, True, 0.0, 4.0),
+        ("llff_white", "llff", 21, 16, True, False, 0.0, 8.0),
+        ("real360_mus", "real360", 25, 64, False, True, 0.5, 5.0),
+        ("blender_empty", "blender", 9, 64, False, True, 0.0, 0.0),
+    ):
+        cfg = load_cfg(CFG_OF[kind], s, s, kind)
+        near, far = float(cfg.dataset.near), float(cfg.dataset.far)
+        _, rd, _, _ = synthetic.make_rays(kind, n, seed=4)
+        t = np.sort(rng.uniform(near, far, (n, s + 1)).astype(np.float32), axis=1)
+        t[:, 0] = near
+        t[:, -1] = far
+        raw = (rng.standard_normal((n, s, 4)) * scale).astype(np.float32)
+        if tag == "blender_empty":
+            raw[..., 3] = -60.0  # softplus underflows: all-zero weights row (0/0 paths)
+        mus = rng.random((n, s)).astype(np.float32) if use_mus else None
+        torch.manual_seed(9)
+        outs = ref_vr.volume_render_radiance_field(T(raw), T(t), T(rd), radiance_field_noise_std=noise_std,
+                                                   white_background=white, mus=None if mus is None else T(mus),
+                                                   cfg=cfg)
+        torch.manual_seed(9)
+        noise = torch.randn((n, s)) * noise_std if noise_std > 0 else None
+        rgb_map, disp, acc, weights, depth, cdisp, rgb = outs
+        save("composite_" + tag, raw=raw, t_vals=t, rd=rd, mus=mus, noise=noise,
+             flags=np.array([int(white), int(kind == "blender")]),
+             rgb_map=rgb_map, disp=disp, acc=acc, weights=weights, depth=depth, cdisp=cdisp, rgb=rgb)
+
+
+# ----------------------------------------------------------------------------------------------
+# 4. hierarchical samplers (a11, a12) with captured bin indices
+# ----------------------------------------------------------------------------------------------
+def weight_profiles(rng, n, nc):
+    """Rows that exercise the sampler: smooth, peaky, one-hot, zero, tied, tiny."""
+    w = np.zeros((n, nc), np.float32)
+    for i in range(n):
+        m = i % 8
+        if m == 0:
+            w[i] = rng.random(nc)
+        elif m == 1:
+            c = rng.integers(0, nc)
+            w[i] = np.exp(-0.5 * ((np.arange(nc) - c) / 0.7) ** 2)
+        elif m == 2:
+            w[i, rng.integers(0, nc)] = 0.9
+        elif m == 3:
+            pass  # all-zero row
+        elif m == 4:
+            w[i] = 0.25  # ties everywhere
+        elif m == 5:
+            w[i] = rng.random(nc) * 1e-12
+        elif m == 6:
+            w[i] = rng.random(nc) ** 8
+        else:
+            w[i, -1] = 1.0
+            w[i, 0] = 0.5
+    return w.astype(np.float32)
+
+
+def capture_gather_index(fn, *args, **kw):
+    """Run fn while recording the index tensor of the first torch.gather call (= bins_ind)."""
+    seen = []
+    orig = torch.gather
+
+    def spy(*a, **k):
+        if not seen:
+            seen.append(k["index"].clone() if "index" in k else a[2].clone())
+        return orig(*a, **k)
+
+    torch.gather = spy
+    try:
+        out = fn(*args, **kw)
+    finally:
+        torch.gather = orig
+    return out, (seen[0] if seen else None)
+
+
+def gen_samplers():
+    rng = np.random.Generator(np.random.PCG64(33))
+    for tag, nc, ns, n, near, far in (("c64f129", 64, 129, 96, 2.0, 6.0), ("c16f17", 16, 17, 40, 0.0, 1.0),
+                                      ("c33f70", 33, 70, 24, 0.2, 2.8), ("c1f9", 1, 9, 8, 2.0, 6.0)):
+        cfg = load_cfg("config_blender.yml", nc, ns - 1)
+        cfg.dataset.near, cfg.dataset.far = near, far
+        bins = np.sort(rng.uniform(near, far, (n, nc + 1)).astype(np.float32), axis=1)
+        bins[:, 0], bins[:, -1] = near, far
+        w = weight_profiles(rng, n, nc)
+        mus = rng.random((n, nc)).astype(np.float32)
+        sig = (rng.random((n, nc)) * 1.2 + 0.001).astype(np.float32)
+        sig[::3] *= 0.02  # narrow in-cell gaussians: z clamp 0.999 and t clip are hit
+        sqrt2 = np.float32(np.sqrt(2.0))
+        left = ref_math.approximate_cdf((0 - T(mus)) / T(sig))
+        part = ref_math.approximate_cdf((1 - T(mus)) / T(sig)) - left
+        out = dict(bins=bins, weights=w, mus=mus, sigmas=sig, left=left, part=part,
+                   meta=np.array([near, far, nc, ns], np.float64))
+        for pad in (True, False):
+            cfg.train_params.pdf_padding = pad
+            for det in (True, False):
+                key = "pad%d_det%d" % (pad, det)
+                torch.manual_seed(13)
+                (s_dd, ind) = capture_gather_index(
+                    ref_samplers.sample_pdf_with_mu_sigma, T(bins), T(w), T(mus), T(sig), part.clone(), left.clone(),
+                    ns, cfg, det=det)
+                torch.manual_seed(13)
+                rnd = torch.rand(n, ns)
+                out["dd_" + key] = s_dd
+                if ind is not None:
+                    out["ddind_" + key] = ind.to(torch.int32)
+                if nc > 1:  # the reference's sample_pdf raises on a single coarse cell (empty cumsum)
+                    torch.manual_seed(13)
+                    s_mip = ref_samplers.sample_pdf(T(bins), T(w), ns, cfg, det=det)
+                    out["mip_" + key] = s_mip
+                if not det:
+                    out["rand"] = rnd
+        out["u_dd_det"] = torch.linspace(0.0, 0.9999, ns)
+        out["u_mip_det"] = torch.linspace(0.0, 1.0, ns)
+        out["arange_dd"] = torch.arange(ns) * (1 / (ns - 1))
+        out["arange_mip"] = torch.arange(ns) * (1 / ns)
+        save("sampler_" + tag, **out)
+
+
+# ----------------------------------------------------------------------------------------------
+# 5. DD head (a8) + dp loss (a13) + whole run_iter, captured from DDNerfModel.predict
+# ----------------------------------------------------------------------------------------------
+class Spy:
+    """Wrap the three free functions DDNerfModel.predict calls so the inline DD-head
+    tensors (models/models.py:242-273) become observable without touching the reference."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def __enter__(self):
+        self.o_s, self.o_d, self.o_v = (ref_models.sample_pdf_with_mu_sigma, ref_models.estimate_dp_loss,
+                                         ref_models.volume_render_radiance_field)
+        rec = self.rec
+
+        def s(bins, weights, mus, sigmas, part, left, ns, cfg, det=True):
+            rec.update(s_bins=bins, s_weights=weights, s_mus=mus, s_ssig=sigmas, s_spart=part, s_sleft=left)
+            out = self.o_s(bins, weights, mus, sigmas, part, left, ns, cfg, det=det)
+            rec["s_out"] = out
+            return out
+
+        def d(t1, t0, w1, w0, mus0, sig0, left0, part0, cfg):
+            rec.update(d_t1=t1, d_t0=t0, d_w1=w1, d_w0=w0, d_mus0=mus0, d_sig0=sig0, d_left0=left0, d_part0=part0)
+            out = self.o_d(t1, t0, w1, w0, mus0, sig0, left0, part0, cfg)
+            rec["d_out"] = out
+            return out
+
+        def v(raw, t, rd, **kw):
+            i = rec.get("v_n", 0)
+            rec["v_n"] = i + 1
+            rec["v%d_raw" % i] = raw
+            rec["v%d_t" % i] = t
+            return self.o_v(raw, t, rd, **kw)
+
+        ref_models.sample_pdf_with_mu_sigma, ref_models.estimate_dp_loss, ref_models.volume_render_radiance_field = s, d, v
+        return self
+
+    def __exit__(self, *a):
+        ref_models.sample_pdf_with_mu_sigma, ref_models.estimate_dp_loss, ref_models.volume_render_radiance_field = (
+            self.o_s, self.o_d, self.o_v)
+
+
+def flat_out(output):
+    res = {}
+    for lvl in output:
+        for k, v in output[lvl].items():
+            if v is None or v is False:
+                continue
+            res["o%d_%s" % (lvl, k)] = v
+    return res
+
+
+def replay_randoms(seed, shapes):
+    """The reference draws, per ray chunk and in this order: rand(first cycle, train only),
+    randn(coarse composite), rand(sampler, non-det only), randn(fine composite)."""
+    torch.manual_seed(seed)
+    out = []
+    for kind, shp in shapes:
+        out.append(torch.rand(shp) if kind == "rand" else torch.randn(shp))
+    return out
+
+
+def gen_runiter():
+    for model_type, kind, n, nc, nf, sharpen, noise in (
+        ("DDNerfModel", "blender", 32, 64, 128, 20.0, 1.0),
+        ("DDNerfModel", "blender", 24, 32, 32, 1.0, 0.0),
+        ("DDNerfModel", "llff", 24, 16, 16, 20.0, 1.0),
+        ("DDNerfModel", "real360", 24, 32, 48, 8.0, 0.0),
+        ("GeneralMipNerfModel", "blender", 24, 64, 128, 20.0, 1.0),
+        ("GeneralMipNerfModel", "llff", 24, 16, 16, 20.0, 0.0),
+    ):
+        cfgname = (CFG_OF if model_type == "DDNerfModel" else CFG_MIP_OF)[kind]
+        cfg = load_cfg(cfgname, nc, nf, kind)
+        for mode in ("train", "validation"):
+            cfg.nerf[mode]["radiance_field_noise_std"] = noise
+        if cfg.train_params.set_automatic_dist_reg_coeficient:  # train_model.py:124-125
+            cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+        model = getattr(ref_models, cfg.nerf.type)(cfg)
+        dd = model_type == "DDNerfModel"
+        load_weights(model.coarse, dd, 11, sharpen)
+        if dd:
+            load_weights(model.fine, False, 12, sharpen)
+        ro, rd, rad, tgt = synthetic.make_rays(kind, n, seed=6)
+        for mode in ("train", "validation"):
+            tag = "runiter_%s_%s_%dx%d_%s" % ("dd" if dd else "mip", kind, nc, nf, mode)
+            perturb = bool(cfg.nerf[mode]["perturb"])
+            shapes = []
+            if perturb:
+                shapes.append(("rand", (n, nc + 1)))
+            if noise > 0:
+                shapes.append(("randn", (n, nc)))
+            if perturb:
+                shapes.append(("rand", (n, nf + 1)))
+            if noise > 0:
+                shapes.append(("randn", (n, nf)))
+            rnd = replay_randoms(17, shapes)
+            torch.manual_seed(17)
+            extra = {}
+            with Spy() as spy:
+                if mode == "train":
+                    model.train()
+                    for p in list(model.coarse.parameters()) + list(model.fine.parameters()):
+                        p.grad = None
+                    out = model.run_iter(T(ro), T(rd), T(rad), mode="train", rgb_target=T(tgt))
+                    loss = 0
+                    for j in range(len(out)):
+                        loss = loss + cfg.train_params.loss_coeficients[j] * torch.nn.functional.mse_loss(out[j]["rgb"], T(tgt))
+                    if dd:
+                        loss = loss + cfg.train_params.dp_coeficient * out[1]["dp_loss"].mean()
+                    loss.backward()
+                    extra["loss"] = loss
+                    nets = [("c", model.coarse)] + ([("f", model.fine)] if dd else [])
+                    for pfx, net in nets:
+                        for name, p in net.named_parameters():
+                            g = p.grad.reshape(-1)
+                            extra["g%s_%s_sub" % (pfx, name)] = g[::61].clone()
+                            extra["g%s_%s_stat" % (pfx, name)] = torch.stack([g.double().norm(), g.double().sum()])
+                else:
+                    model.eval()
+                    with torch.no_grad():
+                        out = model.run_iter(T(ro), T(rd), T(rad), mode="validation", rgb_target=T(tgt))
+            rec = {k: v for k, v in spy.rec.items() if isinstance(v, torch.Tensor)}
+            rnd_named = {"rnd%d" % i: r for i, r in enumerate(rnd)}
+            save(tag, ro=ro, rd=rd, rad=rad, tgt=tgt,
+                 meta=np.array([nc, nf, sharpen, noise, float(cfg.dataset.near), float(cfg.dataset.far),
+                                float(cfg.train_params.dist_reg_coeficient),
+                                float(cfg.train_params.gaussian_smooth_factor), int(cfg.train_params.pdf_padding)]),
+                 **flat_out(out), **rec, **rnd_named, **extra)
+
+
+def gen_dploss():
+    """estimate_dp_loss in isolation, incl. the row-filter misalignment and the all-filtered return."""
+    rng = np.random.Generator(np.random.PCG64(55))
+    for tag, kind, n, nc, nf, drop in (("blender_drop", "blender", 24, 32, 48, True),
+                                       ("blender_full", "blender", 16, 64, 128, False),
+                                       ("llff", "llff", 16, 16, 16, True),
+                                       ("blender_allzero", "blender", 6, 16, 16, "all")):
+        cfg = load_cfg(CFG_OF[kind], nc, nf, kind)
+        near, far = float(cfg.dataset.near), float(cfg.dataset.far)
+        t0 = np.sort(rng.uniform(near, far, (n, nc + 1)).astype(np.float32), 1)
+        t0[:, 0], t0[:, -1] = near, far
+        t1 = np.sort(rng.uniform(near, far, (n, nf + 1)).astype(np.float32), 1)
+        t1[:, 0], t1[:, -1] = near, far
+        w0 = weight_profiles(rng, n, nc) + np.float32(1e-3) * rng.random((n, nc)).astype(np.float32)
+        w1 = (rng.random((n, nf)) ** 4).astype(np.float32)
+        if drop is True:
+            w1[::5] = 0.0
+        elif drop == "all":
+            w1[:] = 0.0
+        mus = rng.random((n, nc)).astype(np.float32)
+        sig = (rng.random((n, nc)) + 0.001).astype(np.float32)
+        left = ref_math.approximate_cdf((0 - T(mus)) / T(sig))
+        part = ref_math.approximate_cdf((1 - T(mus)) / T(sig)) - left
+        w0t, must, sigt = T(w0).requires_grad_(), T(mus).requires_grad_(), T(sig).requires_grad_()
+        loss = ref_dd.estimate_dp_loss(T(t1), T(t0), T(w1), w0t, must, sigt, left, part, cfg)
+        g = {}
+        if loss.requires_grad:
+            loss.backward()
+            g = dict(g_w0=w0t.grad, g_mus=must.grad, g_sig=sigt.grad)
+        save("dploss_" + tag, t1=t1, t0=t0, w1=w1, w0=w0, mus=mus, sig=sig, left=left, part=part,
+             loss=loss.detach().to(torch.float64), is_blender=np.array(int(kind == "blender")), **g)
+
+
+def gen_aten_orders():
+    """Pin the two ATen CPU reduction orders the samplers depend on."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    out = {}
+    for n in (1, 5, 16, 17, 31, 32, 33, 64, 65, 128, 129, 130):
+        x = (rng.random((32, n)) ** 3).astype(np.float32)
+        out["x%d" % n] = x
+        out["sum%d" % n] = torch.sum(T(x), dim=-1)
+        out["cumsum%d" % n] = torch.cumsum(T(x), dim=-1)
+        out["cumprod%d" % n] = torch.cumprod(T(1 - 0.5 * x), dim=-1)
+    save("aten_orders", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders"]
+    for w in which:
+        globals()["gen_" + w]()
