@@ -1,0 +1,56 @@
+"""ctypes binding of libddnerf_hip.so (the C ABI in include/ddnerf_hip.h).
+
+There is no CPU fallback: if the library is missing or a kernel launch fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libddnerf_hip.so")
+
+c_fp = C.c_void_p
+_SIGS = {
+    "ddnerf_abi_version": (C.c_int, []),
+    "ddnerf_error_string": (C.c_char_p, [C.c_int]),
+    "ddnerf_pack_rays": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, C.c_int, c_fp]),
+    "ddnerf_sample_first_cycle": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "ddnerf_encode": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp]),
+    "ddnerf_mlp_f32_packed_floats": (C.c_size_t, [C.c_int]),
+    "ddnerf_mlp_f32_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
+    "ddnerf_mlp_f32_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
+    "ddnerf_dd_head_workspace_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddnerf_dd_head": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_float, C.c_float] + [c_fp] * 9 + [c_fp]),
+    "ddnerf_composite_forward": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int] + [c_fp] * 7 + [c_fp]),
+    "ddnerf_sample_pdf": (C.c_int, [c_fp] * 5 + [C.c_int] * 4 + [c_fp]),
+    "ddnerf_sample_pdf_mu_sigma": (C.c_int, [c_fp] * 8 + [C.c_float, C.c_float, c_fp, c_fp] + [C.c_int] * 4 + [c_fp]),
+}
+
+_lib = None
+
+
+class DDNerfHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise DDNerfHipError(
+                "libddnerf_hip.so not found at %s -- build it with `python -m ddnerf_amd.build` "
+                "(there is no CPU fallback)" % SO_PATH)
+        l = C.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = lib().ddnerf_error_string(code)
+        raise DDNerfHipError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))

@@ -1,0 +1,214 @@
+// K3: alpha compositing (exclusive product scan along the ray) and the DD head.
+// Compiled with -ffp-contract=off so that every product/sum rounds like the reference's ATen CPU ops.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// a10  volume_render_radiance_field  general_utils/volume_rendering_utils.py:6-85
+//      cumprod_exclusive             general_utils/nerf_helpers.py:43-64
+//
+// One 64-lane wave per ray, four rays per 256-thread block.  Lanes stride over the S samples of the ray;
+// per-ray scratch lives in LDS.  The transmittance scan reproduces torch.cumprod's CPU arithmetic
+// (running product in double, each prefix rounded to fp32) by letting one lane run the S-step chain;
+// the three row sums (acc, depth, corrected depth) reproduce torch.sum's 8-lane x 4-accumulator order
+// on 8 lanes of the wave.  Rays are independent, so the cost of those short serial chains is hidden by
+// the other waves resident on the CU.
+// ---------------------------------------------------------------------------------------------------
+#define COMP_WAVES 4
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
+    const float *__restrict__ raw, int ldr, const float *__restrict__ t_vals, const float *__restrict__ rays,
+    const float *__restrict__ noise, const float *__restrict__ mus, int n, int S, int flags,
+    float *__restrict__ rgb_map, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
+    float *__restrict__ depth, float *__restrict__ cdisp, float *__restrict__ rgb_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * COMP_WAVES + wave;
+    const bool live = ray < n;
+    float *alpha = smem + (size_t)wave * 8 * S;  // [S]
+    float *trans = alpha + S;                    // [S]  (1-alpha+1e-10), then exclusive transmittance
+    float *wpre = trans + S;                     // [S]  weights before the blender epsilon
+    float *wpost = wpre + S;                     // [S]  returned weights
+    float *tmp = wpost + S;                      // [S]
+    float *rgbs = tmp + S;                       // [3S]
+    const bool white = flags & DDNERF_COMP_WHITE_BKGD, blender = flags & DDNERF_COMP_BLENDER;
+    const float *t = t_vals + (size_t)(live ? ray : 0) * (S + 1);
+
+    if (live) {
+        const float *d = rays + 12 * (size_t)ray + 3;
+        const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);  // :23
+        for (int j = lane; j < S; j += 64) {
+            const size_t m = (size_t)ray * S + j;
+            const float *r = raw + m * ldr;
+            float delta = (t[j + 1] - t[j]) * dn;                       // :21-23
+            float dens = r[3] + (noise ? noise[m] : 0.0f);              // :40
+            float sig = ddn_softplus(dens - 1.0f);                      // :41
+            float a = 1.0f - expf(-sig * delta);                        // :42
+            alpha[j] = a;
+            trans[j] = 1.0f - a + 1e-10f;                               // :43
+            for (int k = 0; k < 3; ++k) {
+                float c = ddn_sigmoid(r[k]) * 1.002f - 0.001f;          // :25-27
+                rgbs[3 * j + k] = c;
+                if (rgb_out) rgb_out[m * 3 + k] = c;
+            }
+        }
+    }
+    __syncthreads();
+    if (live && lane == 0) {  // exclusive cumprod, double accumulator, fp32 prefixes
+        double p = 1.0;
+        for (int j = 0; j < S; ++j) {
+            float x = trans[j];
+            trans[j] = (float)p;
+            p *= (double)x;
+        }
+    }
+    __syncthreads();
+    if (live) {
+        for (int j = lane; j < S; j += 64) {
+            float w = alpha[j] * trans[j];                              // :43
+            wpre[j] = w;
+            float w2 = (blender && j == S - 1) ? w + 1e-10f : w;        // :52-56
+            wpost[j] = w2;
+            weights[(size_t)ray * S + j] = w2;
+        }
+    }
+    __syncthreads();
+    float c_sum = 0.0f;
+    if (live && lane < 3) {  // rgb_map = sum_j w_j * rgb_j, j ascending (:47-48)
+        for (int j = 0; j < S; ++j) c_sum = c_sum + wpre[j] * rgbs[3 * j + lane];
+    }
+    float wsum = ddn_aten_sum_wave(wpost, S, lane);                     // :58 and :70 (same operand)
+    if (live) {
+        for (int j = lane; j < S; j += 64) {
+            float pdf = blender ? wpost[j] / wsum : wpost[j];           // :58 / :61
+            alpha[j] = pdf;                                             // reuse as pdf
+            tmp[j] = pdf * ((t[j + 1] + t[j]) / 2.0f);                  // :19, :66
+        }
+    }
+    __syncthreads();
+    float dm = ddn_aten_sum_wave(tmp, S, lane);                         // :68
+    __syncthreads();
+    float cdm = 0.0f;
+    if (mus) {                                                          // :77-83
+        if (live)
+            for (int j = lane; j < S; j += 64)
+                tmp[j] = alpha[j] * (t[j] + mus[(size_t)ray * S + j] * (t[j + 1] - t[j]));
+        __syncthreads();
+        cdm = ddn_aten_sum_wave(tmp, S, lane);
+    }
+    if (live) {
+        if (lane < 3) rgb_map[3 * (size_t)ray + lane] = white ? c_sum + (1.0f - wsum) : c_sum;  // :73-74
+        if (lane == 0) {
+            acc[ray] = wsum;
+            disp[ray] = 1.0f / fmaxf(1e-10f, dm / wsum);                // :71
+            if (mus) {
+                if (cdisp) cdisp[ray] = 1.0f / fmaxf(1e-10f, cdm / wsum);  // :82
+                depth[ray] = cdm;                                       // :83
+            } else {
+                depth[ray] = dm;
+            }
+        }
+    }
+}
+
+DDN_EXPORT int ddnerf_composite_forward(const float *raw, int ldr, const float *t_vals, const float *rays,
+                                        const float *noise, const float *mus, int n, int S, int flags, float *rgb_map,
+                                        float *disp, float *acc, float *weights, float *depth, float *cdisp,
+                                        float *rgb, ddnerf_stream_t stream) {
+    DDN_REQUIRE(raw && t_vals && rays && rgb_map && disp && acc && weights && depth, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ldr >= 4, DDNERF_E_RANGE);
+    size_t lds = (size_t)COMP_WAVES * 8 * S * sizeof(float);
+    DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);  // S <= 512
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds,
+                       (hipStream_t)stream, raw, ldr, t_vals, rays, noise, mus, n, S, flags, rgb_map, disp, acc,
+                       weights, depth, cdisp, rgb);
+    return ddn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a8  DD head   models/models.py:242-260 (raw sigma) and :266-273 (smoothed sigma)
+// Elementwise part + the two L2 regularisers (sum of squares over the whole chunk divided by the number
+// of rays).  Reduction is two-stage and order-fixed (no atomics) so training is reproducible.
+// ---------------------------------------------------------------------------------------------------
+#define DDH_BLOCK 256
+
+__global__ __launch_bounds__(DDH_BLOCK) void dd_head_kernel(const float *__restrict__ raw6, size_t count, float smooth,
+                                                            float *__restrict__ mus, float *__restrict__ sigmas,
+                                                            float *__restrict__ left, float *__restrict__ part,
+                                                            float *__restrict__ ssig, float *__restrict__ sleft,
+                                                            float *__restrict__ spart, float *__restrict__ partials) {
+    __shared__ float red[2][DDH_BLOCK];
+    size_t i = (size_t)blockIdx.x * DDH_BLOCK + threadIdx.x;
+    float sq_m = 0.0f, sq_s = 0.0f;
+    if (i < count) {
+        float rm = raw6[6 * i + 4], rs = raw6[6 * i + 5];
+        float mu = ddn_sigmoid(rm), sg = ddn_sigmoid(rs) + 0.001f;       // :245-246
+        mus[i] = mu;
+        sigmas[i] = sg;
+        sq_m = fabsf(rm) * fabsf(rm);                                     // :249
+        sq_s = fabsf(rs) * fabsf(rs);                                     // :248
+        float l = ddn_norm_cdf((0.0f - mu) / sg);                         // :254-257
+        left[i] = l;
+        part[i] = ddn_norm_cdf((1.0f - mu) / sg) - l;                     // :258
+        float ss = sg * smooth;                                           // :268
+        ssig[i] = ss;
+        float sl = ddn_norm_cdf((0.0f - mu) / ss);                        // :270-272
+        sleft[i] = sl;
+        spart[i] = ddn_norm_cdf((1.0f - mu) / ss) - sl;                   // :273
+    }
+    red[0][threadIdx.x] = sq_m;
+    red[1][threadIdx.x] = sq_s;
+    __syncthreads();
+    for (int s = DDH_BLOCK / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = red[0][0];
+        partials[2 * blockIdx.x + 1] = red[1][0];
+    }
+}
+
+__global__ void dd_head_finish_kernel(const float *__restrict__ partials, int nblocks, int n, float dist_reg,
+                                      float *__restrict__ scal) {
+    // one wave; lane-strided double partials, then a fixed-order tree
+    double m = 0.0, s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) {
+        m += (double)partials[2 * b];
+        s += (double)partials[2 * b + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m += __shfl_down(m, o);
+        s += __shfl_down(s, o);
+    }
+    if (threadIdx.x == 0) {
+        float ml = (float)m / (float)n, sl = (float)s / (float)n;        // :248-249 (rays in chunk)
+        scal[0] = ml;
+        scal[1] = sl;
+        scal[2] = dist_reg * ml;                                          // :251
+        scal[3] = dist_reg * sl;                                          // :252
+    }
+}
+
+DDN_EXPORT size_t ddnerf_dd_head_workspace_floats(int n, int nc) {
+    if (n <= 0 || nc <= 0) return 0;
+    size_t count = (size_t)n * nc;
+    return 2 * ((count + DDH_BLOCK - 1) / DDH_BLOCK);
+}
+
+DDN_EXPORT int ddnerf_dd_head(const float *raw6, int n, int nc, float smooth, float dist_reg, float *mus,
+                              float *sigmas, float *left, float *part, float *ssig, float *sleft, float *spart,
+                              float *scal, float *workspace, ddnerf_stream_t stream) {
+    DDN_REQUIRE(raw6 && mus && sigmas && left && part && ssig && sleft && spart && scal && workspace, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    size_t count = (size_t)n * nc;
+    int nblocks = (int)((count + DDH_BLOCK - 1) / DDH_BLOCK);
+    hipLaunchKernelGGL(dd_head_kernel, dim3(nblocks), dim3(DDH_BLOCK), 0, (hipStream_t)stream, raw6, count, smooth, mus,
+                       sigmas, left, part, ssig, sleft, spart, workspace);
+    hipLaunchKernelGGL(dd_head_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, nblocks, n, dist_reg,
+                       scal);
+    return ddn_launch_status();
+}

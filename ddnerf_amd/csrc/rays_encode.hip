@@ -1,0 +1,221 @@
+// Ray packing, first-cycle sampling and the fused cone-cast + IPE + view-dir encoding kernel (K1).
+// Compiled with -ffp-contract=off: the Gaussian mean feeds sin(x * 2^l) with l up to 15, so the
+// reference's operation order must be kept bit for bit (SURVEY.md 7 "hard parts").
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// a1  GeneralMipNerfModel.get_rays_batches   models/models.py:144-162
+// ---------------------------------------------------------------------------------------------------
+__global__ void pack_rays_kernel(const float *__restrict__ ro, const float *__restrict__ rd,
+                                 const float *__restrict__ rad, float near_, float far_, float *__restrict__ rays,
+                                 int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d0 = rd[3 * i], d1 = rd[3 * i + 1], d2 = rd[3 * i + 2];
+    float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    float *r = rays + 12 * (size_t)i;
+    r[0] = ro[3 * i]; r[1] = ro[3 * i + 1]; r[2] = ro[3 * i + 2];
+    r[3] = d0; r[4] = d1; r[5] = d2;
+    r[6] = rad[i];
+    r[7] = near_; r[8] = far_;
+    r[9] = d0 / nrm; r[10] = d1 / nrm; r[11] = d2 / nrm;
+}
+
+DDN_EXPORT int ddnerf_pack_rays(const float *origins, const float *directions, const float *radii, float near_,
+                                float far_, float *rays, int n, ddnerf_stream_t stream) {
+    DDN_REQUIRE(origins && directions && radii && rays, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0, DDNERF_E_ARG);
+    hipLaunchKernelGGL(pack_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, origins, directions,
+                       radii, near_, far_, rays, n);
+    return ddn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a2  sample_first_cycle   models/samplers.py:30-62.  One thread per fencepost.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float first_cycle_t(float nr, float fr, float tl, int lindisp) {
+    if (!lindisp) return nr * (1.0f - tl) + fr * tl;             // :40
+    return 1.0f / (1.0f / nr * (1.0f - tl) + 1.0f / fr * tl);    // :42
+}
+
+__global__ void first_cycle_kernel(const float *__restrict__ rays, const float *__restrict__ t_lin,
+                                   const float *__restrict__ t_rand, float *__restrict__ t_vals, int n, int nc,
+                                   int lindisp) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int s1 = nc + 1;
+    if (idx >= (size_t)n * s1) return;
+    int i = (int)(idx / s1), j = (int)(idx % s1);
+    float nr = rays[12 * (size_t)i + 7], fr = rays[12 * (size_t)i + 8];
+    float t = first_cycle_t(nr, fr, t_lin[j], lindisp);
+    if (t_rand) {  // :52-60
+        float lower, upper;
+        if (j == 0) lower = t;
+        else lower = 0.5f * (t + first_cycle_t(nr, fr, t_lin[j - 1], lindisp));
+        if (j == nc) upper = t;
+        else upper = 0.5f * (first_cycle_t(nr, fr, t_lin[j + 1], lindisp) + t);
+        t = lower + (upper - lower) * t_rand[idx];
+        if (j == 0) t = nr;
+        if (j == nc) t = fr;
+    }
+    t_vals[idx] = t;
+}
+
+DDN_EXPORT int ddnerf_sample_first_cycle(const float *rays, const float *t_lin, const float *t_rand, float *t_vals,
+                                         int n, int nc, int lindisp, ddnerf_stream_t stream) {
+    DDN_REQUIRE(rays && t_lin && t_vals, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    size_t total = (size_t)n * (nc + 1);
+    hipLaunchKernelGGL(first_cycle_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays, t_lin, t_rand, t_vals, n, nc, lindisp);
+    return ddn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1  encode: cast_rays -> conical_frustum_to_gaussian(stable) | cylinder_to_gaussian -> lift_gaussian(diag)
+//     -> integrated_pos_enc(16 octaves) -> cat(view-dir positional encoding)
+//     general_utils/math_utils.py:7-166, general_utils/nerf_helpers.py:127-171, models/models.py:124-133
+//
+// Work split: one thread per (sample, octave*3+axis) pair, 48 threads per sample: the thread evaluates the
+// shared damping exp(-yv/2) once and both the sin and the cos-block feature.  A 256-thread block covers
+// 16 samples x 16 "slots"(= 3 features each); the per-sample Gaussian (mean[3], cov[3]) is computed once per
+// sample by 16 threads and shared through LDS.  Rows are written 128 columns wide so that the MLP kernel can
+// fetch them as aligned 16-byte pieces; stores are issued column-contiguous per sample (coalesced 512 B rows).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gaussian_of_interval(float t0, float t1, float rad, int cylinder, float &t_mean,
+                                                     float &t_var, float &r_var) {
+    if (!cylinder) {
+        float mu = (t0 + t1) / 2.0f, hw = (t1 - t0) / 2.0f;
+        float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+        float den = 3.0f * mu2 + hw2;
+        t_mean = mu + (2.0f * mu * hw2) / den;                                                      // :78
+        t_var = hw2 / 3.0f - 0.266666681f * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));            // :79-80
+        r_var = (rad * rad) * ((mu2 / 4.0f + 0.416666657f * hw2) - 0.266666681f * hw4 / den);       // :81-82
+    } else {
+        float dt = t1 - t0;
+        t_mean = (t0 + t1) / 2.0f;   // :107
+        r_var = (rad * rad) / 4.0f;  // :108
+        t_var = (dt * dt) / 12.0f;   // :109
+    }
+}
+
+// torch.remainder(x, T), T > 0
+__device__ __forceinline__ float remainder_pos(float x, float T) {
+    float r = fmodf(x, T);
+    if (r != 0.0f && r < 0.0f) r += T;
+    return r;
+}
+
+__device__ __forceinline__ float safe_sin(float x) {
+    const float T = 314.159271f;  // 100 * fp32(pi), general_utils/math_utils.py:155
+    float xr = (fabsf(x) < T) ? x : remainder_pos(x, T);
+    return sinf(xr);
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+#define ENC_SPB 16  // samples per 256-thread block
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ rays, const float *__restrict__ t_vals,
+                                                     void *__restrict__ feat_, int n, int S, int cylinder) {
+    __shared__ float g_mean[ENC_SPB][4];
+    __shared__ float g_cov[ENC_SPB][4];
+    __shared__ float row[ENC_SPB][DDNERF_FEAT_LD];
+    const size_t M = (size_t)n * S;
+    const size_t m0 = (size_t)blockIdx.x * ENC_SPB;
+    const int tid = threadIdx.x;
+
+    // phase 1: per-sample Gaussian, threads 0..47 (sample = tid/3, axis = tid%3)
+    if (tid < ENC_SPB * 3) {
+        int ls = tid / 3, a = tid % 3;
+        size_t m = m0 + ls;
+        if (m < M) {
+            int i = (int)(m / S), j = (int)(m % S);
+            const float *r = rays + 12 * (size_t)i;
+            const float *t = t_vals + (size_t)i * (S + 1) + j;
+            float tm, tv, rv;
+            gaussian_of_interval(t[0], t[1], r[6], cylinder, tm, tv, rv);
+            float d0 = r[3], d1 = r[4], d2 = r[5];
+            float q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+            float dmag = fmaxf(1e-10f, (q0 + q1) + q2);                       // :38
+            float da = r[3 + a], qa = da * da;
+            float nul = 1.0f - qa / dmag;                                     // :42
+            g_mean[ls][a] = da * tm + r[a];                                   // :36, :30
+            g_cov[ls][a] = tv * qa + rv * nul;                                // :43-45
+        }
+    }
+    // phase 1b: view-direction encoding, threads 64..(64+16*27): 27 values per sample (same for a ray's samples)
+    {
+        int t2 = tid - 64;
+        if (t2 >= 0 && t2 < ENC_SPB * 12) {
+            int ls = t2 / 12, k = t2 % 12;  // k: 0..11 -> (freq f = k/3, axis a = k%3), emits sin and cos
+            size_t m = m0 + ls;
+            if (m < M) {
+                int i = (int)(m / S);
+                int f = k / 3, a = k % 3;
+                float v = rays[12 * (size_t)i + 9 + a];
+                float x = v * (float)(1 << f);                                // nerf_helpers.py:163-165
+                row[ls][96 + 3 + f * 6 + a] = sinf(x);
+                row[ls][96 + 3 + f * 6 + 3 + a] = cosf(x);
+                if (f == 0) row[ls][96 + a] = v;                              // include_input
+                if (k < 5) row[ls][123 + k] = 0.0f;                           // pad columns
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: IPE, 3 threads-rounds of 256: thread -> (sample ls, pair p in 0..47)
+    for (int e = tid; e < ENC_SPB * 48; e += 256) {
+        int ls = e / 48, p = e % 48;
+        if (m0 + ls < M) {
+            int l = p / 3, a = p % 3;
+            float s = (float)(1 << l);
+            float y = g_mean[ls][a] * s;                                      // :130
+            float yv = g_cov[ls][a] * (s * s);                                // :131
+            float damp = expf(-0.5f * yv);                                    // :149
+            row[ls][p] = damp * safe_sin(y);
+            row[ls][48 + p] = damp * safe_sin(y + 1.57079637f);               // :143  y + 0.5*fp32(pi)
+        }
+    }
+    __syncthreads();
+    // phase 3: coalesced row stores (16 rows x 128 columns)
+    if (BF16) {
+        unsigned short *feat = (unsigned short *)feat_;
+        for (int e = tid; e < ENC_SPB * DDNERF_FEAT_LD / 2; e += 256) {
+            int ls = e / (DDNERF_FEAT_LD / 2), c = (e % (DDNERF_FEAT_LD / 2)) * 2;
+            if (m0 + ls < M) {
+                unsigned v = (unsigned)f32_to_bf16(row[ls][c]) | ((unsigned)f32_to_bf16(row[ls][c + 1]) << 16);
+                *(unsigned *)(feat + (m0 + ls) * DDNERF_FEAT_LD + c) = v;
+            }
+        }
+    } else {
+        float *feat = (float *)feat_;
+        for (int e = tid; e < ENC_SPB * DDNERF_FEAT_LD / 4; e += 256) {
+            int ls = e / (DDNERF_FEAT_LD / 4), c = (e % (DDNERF_FEAT_LD / 4)) * 4;
+            if (m0 + ls < M) {
+                float4 v = make_float4(row[ls][c], row[ls][c + 1], row[ls][c + 2], row[ls][c + 3]);
+                *(float4 *)(feat + (m0 + ls) * DDNERF_FEAT_LD + c) = v;
+            }
+        }
+    }
+}
+
+DDN_EXPORT int ddnerf_encode(const float *rays, const float *t_vals, void *feat, int n, int S, int ray_shape,
+                             int feat_dtype, ddnerf_stream_t stream) {
+    DDN_REQUIRE(rays && t_vals && feat, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ray_shape == 0 || ray_shape == 1, DDNERF_E_RANGE);
+    DDN_REQUIRE(feat_dtype == 0 || feat_dtype == 1, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(feat, 16), DDNERF_E_ALIGN);
+    size_t M = (size_t)n * S;
+    dim3 grid((unsigned)((M + ENC_SPB - 1) / ENC_SPB));
+    if (feat_dtype == 0)
+        hipLaunchKernelGGL(encode_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S,
+                           ray_shape);
+    else
+        hipLaunchKernelGGL(encode_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S,
+                           ray_shape);
+    return ddn_launch_status();
+}

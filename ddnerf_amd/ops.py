@@ -1,0 +1,139 @@
+"""Tensor-level wrappers of the HIP kernels (one function per C-ABI entry point).
+
+Every function takes/returns torch tensors that live on the GPU, allocates outputs with torch, and
+enqueues the kernel on torch's current stream.  No function has a CPU path."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+FEAT_LD = 128
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.DDNerfHipError("%s must be a GPU tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def pack_rays(origins, directions, radii, near, far):
+    """models/models.py:144-162 -> rays [n,12]"""
+    o = _f32c(origins, "origins").reshape(-1, 3)
+    d = _f32c(directions, "directions").reshape(-1, 3)
+    r = _f32c(radii, "radii").reshape(-1)
+    n = o.shape[0]
+    rays = torch.empty((n, 12), dtype=torch.float32, device=o.device)
+    _lib.check(_lib.lib().ddnerf_pack_rays(_ptr(o), _ptr(d), _ptr(r), float(near), float(far), _ptr(rays), n, _stream()),
+               "ddnerf_pack_rays")
+    return rays
+
+
+def sample_first_cycle(rays, t_lin, t_rand=None, lindisp=False):
+    """models/samplers.py:30-62 -> t_vals [n,nc+1]"""
+    rays, t_lin, t_rand = _f32c(rays, "rays"), _f32c(t_lin, "t_lin"), _f32c(t_rand, "t_rand")
+    n, nc = rays.shape[0], t_lin.shape[0] - 1
+    t = torch.empty((n, nc + 1), dtype=torch.float32, device=rays.device)
+    _lib.check(_lib.lib().ddnerf_sample_first_cycle(_ptr(rays), _ptr(t_lin), _ptr(t_rand), _ptr(t), n, nc, int(lindisp),
+                                                    _stream()), "ddnerf_sample_first_cycle")
+    return t
+
+
+def encode(rays, t_vals, cylinder=False, bf16=False):
+    """cast_rays + integrated_pos_enc + view-dir encoding -> feat [n*S,128] (fp32 or bf16)"""
+    rays, t_vals = _f32c(rays, "rays"), _f32c(t_vals, "t_vals")
+    n, S = t_vals.shape[0], t_vals.shape[1] - 1
+    feat = torch.empty((n * S, FEAT_LD), dtype=torch.bfloat16 if bf16 else torch.float32, device=rays.device)
+    _lib.check(_lib.lib().ddnerf_encode(_ptr(rays), _ptr(t_vals), _ptr(feat), n, S, int(cylinder), int(bf16), _stream()),
+               "ddnerf_encode")
+    return feat
+
+
+def mlp_f32_pack(params_flat, depth_head):
+    params_flat = _f32c(params_flat, "params")
+    nfl = _lib.lib().ddnerf_mlp_f32_packed_floats(int(depth_head))
+    packed = torch.empty(nfl, dtype=torch.float32, device=params_flat.device)
+    _lib.check(_lib.lib().ddnerf_mlp_f32_pack(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()),
+               "ddnerf_mlp_f32_pack")
+    return packed
+
+
+def mlp_f32_forward(feat, packed, depth_head):
+    """models/base_architectures.py:40-61 / 103-126: feat [M,128] -> raw [M,4|6]"""
+    feat = _f32c(feat, "feat")
+    M = feat.shape[0]
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+    _lib.check(_lib.lib().ddnerf_mlp_f32_forward(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), M, _stream()),
+               "ddnerf_mlp_f32_forward")
+    return raw
+
+
+def dd_head(raw6, smooth, dist_reg):
+    """models/models.py:242-260, 266-273.  raw6 [n,nc,6]"""
+    raw6 = _f32c(raw6, "raw6")
+    n, nc = raw6.shape[0], raw6.shape[1]
+    dev = raw6.device
+    outs = [torch.empty((n, nc), dtype=torch.float32, device=dev) for _ in range(7)]
+    scal = torch.empty(4, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(1, _lib.lib().ddnerf_dd_head_workspace_floats(n, nc)), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().ddnerf_dd_head(_ptr(raw6), n, nc, float(smooth), float(dist_reg), *[_ptr(o) for o in outs],
+                                         _ptr(scal), _ptr(ws), _stream()), "ddnerf_dd_head")
+    d = dict(zip(("mus", "sigmas", "left", "part", "ssig", "sleft", "spart"), outs))
+    d["scal"] = scal  # mus_loss, sig_loss, mus_reg, sig_reg
+    return d
+
+
+def composite_forward(raw, t_vals, rays, noise=None, mus=None, white_bkgd=False, blender=True, want_rgb=False):
+    """general_utils/volume_rendering_utils.py:6-85.  raw [n,S,4|6]"""
+    raw, t_vals, rays = _f32c(raw, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays")
+    noise, mus = _f32c(noise, "noise"), _f32c(mus, "mus")
+    n, S, ldr = raw.shape
+    dev = raw.device
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    o = dict(rgb_map=e(n, 3), disp=e(n), acc=e(n), weights=e(n, S), depth=e(n), cdisp=e(n) if mus is not None else None,
+             rgb=e(n, S, 3) if want_rgb else None)
+    flags = (1 if white_bkgd else 0) | (2 if blender else 0)
+    _lib.check(_lib.lib().ddnerf_composite_forward(_ptr(raw), ldr, _ptr(t_vals), _ptr(rays), _ptr(noise), _ptr(mus), n, S,
+                                                   flags, _ptr(o["rgb_map"]), _ptr(o["disp"]), _ptr(o["acc"]),
+                                                   _ptr(o["weights"]), _ptr(o["depth"]), _ptr(o["cdisp"]), _ptr(o["rgb"]),
+                                                   _stream()), "ddnerf_composite_forward")
+    return o
+
+
+def sample_pdf(bins, weights, u_base, rnd, pdf_padding):
+    """models/samplers.py:64-121 -> samples [n,ns]"""
+    bins, weights, u_base, rnd = _f32c(bins, "bins"), _f32c(weights, "weights"), _f32c(u_base, "u_base"), _f32c(rnd, "rnd")
+    n, nc = weights.shape
+    ns = u_base.shape[0]
+    out = torch.empty((n, ns), dtype=torch.float32, device=bins.device)
+    _lib.check(_lib.lib().ddnerf_sample_pdf(_ptr(bins), _ptr(weights), _ptr(u_base), _ptr(rnd), _ptr(out), n, nc, ns,
+                                            int(pdf_padding), _stream()), "ddnerf_sample_pdf")
+    return out
+
+
+def sample_pdf_mu_sigma(bins, weights, mus, sigmas, part, left, u_base, rnd, near, far, pdf_padding, want_ind=False):
+    """models/samplers.py:124-215 -> samples [n,ns] (sorted) [, bins_ind int32 [n,ns]]"""
+    bins, weights, mus, sigmas, part, left, u_base, rnd = (
+        _f32c(t, k) for t, k in ((bins, "bins"), (weights, "weights"), (mus, "mus"), (sigmas, "sigmas"), (part, "part"),
+                                 (left, "left"), (u_base, "u_base"), (rnd, "rnd")))
+    n, nc = weights.shape
+    ns = u_base.shape[0]
+    out = torch.empty((n, ns), dtype=torch.float32, device=bins.device)
+    ind = torch.empty((n, ns), dtype=torch.int32, device=bins.device) if want_ind else None
+    _lib.check(_lib.lib().ddnerf_sample_pdf_mu_sigma(_ptr(bins), _ptr(weights), _ptr(mus), _ptr(sigmas), _ptr(part),
+                                                     _ptr(left), _ptr(u_base), _ptr(rnd), float(near), float(far),
+                                                     _ptr(out), _ptr(ind), n, nc, ns, int(pdf_padding), _stream()),
+               "ddnerf_sample_pdf_mu_sigma")
+    return (out, ind) if want_ind else out

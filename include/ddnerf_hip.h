@@ -1,0 +1,116 @@
+/*
+ * ddnerf_hip.h -- C ABI of libddnerf_hip.so: DDNeRF's ray-march hot path as hand-written
+ * HIP kernels for MI355X (gfx950 / CDNA4).
+ *
+ * The reference has no FFI of its own: its operator API for this path is the set of pure
+ * tensor functions that models/models.py calls.  Each entry point below replaces
+ * one of those functions (cited as path:line in the reference repository) and is what a
+ * binding inside the reference would call instead (INTEGRATION.md shows the ctypes stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked [host]; tensors are dense, row-major, fp32
+ *     unless stated; the library never allocates, never synchronises and never throws
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); work is enqueued on it
+ *     and the caller keeps all buffers alive until the stream has passed them
+ *   - random / linspace tensors (torch.rand, torch.randn, torch.linspace) are produced by the host
+ *     framework and passed in, exactly like the reference draws them
+ *   - return value: 0 = success; DDNERF_E_* (<0) = rejected arguments; >0 = hipError_t of the launch
+ *   - the library is stateless (thread-safe); weights are passed per call
+ *
+ * Ray row layout ("rays", [n,12], models/models.py:158):
+ *      [origin 0:3 | direction 3:6 | radius 6 | near 7 | far 8 | unit view direction 9:12]
+ * Feature row layout ("feat", [M,128], M = n*S):
+ *      [IPE sin block 0:48 | IPE cos block 48:96 | view-dir encoding 96:123 | zeros 123:128]
+ *      = the reference's `embedded` [M,123] (models/models.py:133) padded to 128 columns.
+ * Flat parameter buffer ("params"): the network's parameters in registration order
+ *      layers_xyz.0..7, fc_feat, fc_alpha, layers_dir.0, fc_rgb [, fc_mu_sigma], each weight
+ *      [out][in] row-major followed by its bias (models/base_architectures.py:22-37, 83-99):
+ *      612,740 floats (MipNeRFModel) / 612,998 floats (DepthMipNeRFModel).
+ */
+#ifndef DDNERF_HIP_H
+#define DDNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ddnerf_stream_t;
+
+#define DDNERF_OK 0
+#define DDNERF_E_ARG (-1)       /* null pointer / non-positive size */
+#define DDNERF_E_RANGE (-2)     /* size outside what the kernel was built for */
+#define DDNERF_E_ALIGN (-3)     /* pointer not aligned as required */
+#define DDNERF_E_WORKSPACE (-4) /* workspace too small */
+
+#define DDNERF_FEAT_LD 128          /* columns of a feature row */
+#define DDNERF_PARAMS_FINE 612740   /* floats in MipNeRFModel's flat parameter buffer */
+#define DDNERF_PARAMS_COARSE_DD 612998
+
+int ddnerf_abi_version(void);
+const char *ddnerf_error_string(int code);
+
+/* a1  GeneralMipNerfModel.get_rays_batches   models/models.py:144-162 */
+int ddnerf_pack_rays(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                     float *rays, int n, ddnerf_stream_t stream);
+
+/* a2  sample_first_cycle   models/samplers.py:30-62
+ * t_lin [nc+1] = torch.linspace(0,1,nc+1); t_rand [n,nc+1] = torch.rand(...) or NULL (perturb off). */
+int ddnerf_sample_first_cycle(const float *rays, const float *t_lin, const float *t_rand, float *t_vals, int n, int nc,
+                              int lindisp, ddnerf_stream_t stream);
+
+/* a3+a4+a5  cast_rays -> integrated_pos_enc, positional_encoding(view dirs), concat
+ * general_utils/math_utils.py:7-166, general_utils/nerf_helpers.py:127-171, models/models.py:124-133
+ * t_vals [n,S+1] -> feat [n*S,128].  ray_shape: 0 cone, 1 cylinder.  feat_dtype: 0 fp32, 1 bf16. */
+int ddnerf_encode(const float *rays, const float *t_vals, void *feat, int n, int S, int ray_shape, int feat_dtype,
+                  ddnerf_stream_t stream);
+
+/* a7  MipNeRFModel.forward / DepthMipNeRFModel.forward  models/base_architectures.py:40-61, 103-126
+ * as ONE fused kernel (all 12/13 Linear layers, activations never leave the register file).
+ *   step 1: repack the flat fp32 parameters into the kernel's LDS-image layout (once per weight update)
+ *   step 2: forward: feat [M,128] -> raw [M,4] (rgb, alpha) or [M,6] (+ raw mu, raw sigma) */
+size_t ddnerf_mlp_f32_packed_floats(int depth_head);
+int ddnerf_mlp_f32_pack(const float *params, int depth_head, float *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_f32_forward(const float *feat, const float *packed, int depth_head, float *raw, long M,
+                           ddnerf_stream_t stream);
+
+/* a8  DD head, inline in DDNerfModel.predict  models/models.py:242-260, 266-273
+ * raw6 [n,nc,6] -> mus, sigmas, left_tail, part_inside (raw sigma) and smoothed sigma/left/part, all [n,nc];
+ * scal[4] = {mus_loss, sig_loss, mus_reg, sig_reg}.  workspace: ddnerf_dd_head_workspace_floats() floats. */
+size_t ddnerf_dd_head_workspace_floats(int n, int nc);
+int ddnerf_dd_head(const float *raw6, int n, int nc, float smooth, float dist_reg, float *mus, float *sigmas,
+                   float *left, float *part, float *ssig, float *sleft, float *spart, float *scal, float *workspace,
+                   ddnerf_stream_t stream);
+
+/* a10  volume_render_radiance_field  general_utils/volume_rendering_utils.py:6-85 (+ cumprod_exclusive,
+ * general_utils/nerf_helpers.py:43-64).  raw [n,S,ldr] (ldr 4 or 6: columns 0:3 rgb, 3 density).
+ * noise [n,S] = randn*std or NULL; mus [n,S] or NULL (then cdisp may be NULL).
+ * flags: bit0 white background, bit1 blender branch (weights[-1]+=1e-10, depth from normalised pdf).
+ * outputs: rgb_map [n,3], disp [n], acc [n], weights [n,S], depth [n], cdisp [n], rgb [n,S,3] (may be NULL). */
+#define DDNERF_COMP_WHITE_BKGD 1
+#define DDNERF_COMP_BLENDER 2
+int ddnerf_composite_forward(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
+                             const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc,
+                             float *weights, float *depth, float *cdisp, float *rgb, ddnerf_stream_t stream);
+
+/* a11  sample_pdf  models/samplers.py:64-121
+ * u_base [ns]: perturb off -> torch.linspace(0,1,ns); on -> torch.arange(ns)*(1/ns).
+ * rnd [n,ns] = torch.rand(n,ns) or NULL; then u = min(u_base + rnd/fp32(ns+1e-5), 0.9999). */
+int ddnerf_sample_pdf(const float *bins, const float *weights, const float *u_base, const float *rnd, float *samples,
+                      int n, int nc, int ns, int pdf_padding, ddnerf_stream_t stream);
+
+/* a12  sample_pdf_with_mu_sigma  models/samplers.py:124-215
+ * mus/sigmas/part/left: the (smoothed) per-bin quantities the caller passes (models/models.py:227-237).
+ * u_base [ns]: perturb off -> torch.linspace(0,0.9999,ns); on -> torch.arange(ns)*(1/(ns-1)).
+ * samples [n,ns] sorted; bins_ind [n,ns] int32 (may be NULL) = the bin index of each draw BEFORE the sort. */
+int ddnerf_sample_pdf_mu_sigma(const float *bins, const float *weights, const float *mus, const float *sigmas,
+                               const float *part, const float *left, const float *u_base, const float *rnd,
+                               float near_, float far_, float *samples, int32_t *bins_ind, int n, int nc, int ns,
+                               int pdf_padding, ddnerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDNERF_HIP_H */

@@ -1,0 +1,50 @@
+"""Helpers shared by the CPU (oracle) and GPU (HIP) parity tests: rebuild the exact inputs of a
+golden `runiter_*` case (weights from seeds, random tensors from the fixture, torch linspace rows)."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+from ddnerf_amd import synthetic
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def runiter_names():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "runiter_*.npz")))
+
+
+def load_runiter(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    _, mt, kind, _, mode = name.split("_")
+    nc, nf, sharpen, noise, near, far, dist_reg, smooth, pad = g["meta"]
+    dd = mt == "dd"
+    train = mode == "train"
+    rnd = [g[k] for k in sorted((k for k in g if k.startswith("rnd")), key=lambda s: int(s[3:]))]
+    it = iter(rnd)
+    # draw order of the reference, per chunk: rand(first cycle) / randn(coarse) / rand(sampler) / randn(fine)
+    t_rand = next(it) if train else None
+    noise0 = next(it) * np.float32(noise) if noise > 0 else None
+    u_rand = next(it) if train else None
+    noise1 = next(it) * np.float32(noise) if noise > 0 else None
+    case = dict(
+        g=g, dd=dd, kind=kind, mode=mode, train=train, nc=int(nc), nf=int(nf), sharpen=float(sharpen), noise=float(noise),
+        near=float(near), far=float(far), dist_reg=float(dist_reg), smooth=float(smooth), pdf_padding=bool(pad),
+        blender=(kind == "blender"), t_rand=t_rand, noise0=noise0, u_rand=u_rand, noise1=noise1,
+        t_lin=torch.linspace(0.0, 1.0, int(nc) + 1).numpy(),
+        u_det=torch.linspace(0.0, 0.9999 if dd else 1.0, int(nf) + 1).numpy(),
+        sd_coarse=synthetic.make_state_dict(dd, 11, sharpen),
+        sd_fine=synthetic.make_state_dict(False, 12, sharpen) if dd else None,
+    )
+    return case
+
+
+def maxerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN pattern differs"
+    return float(np.nanmax(np.abs(a - b))) if np.isfinite(a).any() else 0.0
