@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the DDNeRF ray-march hot path on MI355X (contract: see the task's bench.py section).
+
+A "step" is one pass of the hot path over one batch of synthetic rays: `model.run_iter(...)` of the HIP-backed
+`DDNerfModel` at BASELINE.json configs[1] -- config_blender.yml, 4096 rays x (64 coarse + 128 fine) samples,
+8x256 MLPs, fp32 -- per GPU (weak scaling: every rank renders its own 4096-ray batch, no data-path collective
+in render mode; train mode adds the RCCL gradient all-reduce).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 with the metric, a `roofline` object for the dominant kernel (the fused fine-MLP
+forward: algorithmic FLOP per launch / mean launch duration measured with HIP events on the launch stream) and,
+at N=1, a `cpu_baseline` object (the CPU oracle timed on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_FINE = 1220608       # per sample, MipNeRFModel forward
+FLOP_COARSE_DD = 1221120  # per sample, DepthMipNeRFModel forward
+PEAK = {"fp32": 157.3, "bf16": 2500.0}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    p.add_argument("--coarse", type=int, default=64)
+    p.add_argument("--fine", type=int, default=128)
+    p.add_argument("--mode", choices=["render", "train"], default="render")
+    p.add_argument("--mlp", choices=["fp32", "bf16"], default="fp32")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-rays", type=int, default=512, help="rays of the same workload timed on the CPU oracle")
+    return p.parse_args()
+
+
+def build_model(args, device):
+    from ddnerf_amd import synthetic
+    from ddnerf_amd.cfgnode import CfgNode
+    from models import models
+
+    cfg = CfgNode.load(os.path.join(ROOT, "configs", "config_blender.yml"))
+    for mode in ("train", "validation"):
+        cfg.nerf[mode]["num_coarse"] = args.coarse
+        cfg.nerf[mode]["num_fine"] = args.fine
+    cfg.nerf["mlp_dtype"] = args.mlp
+    cfg.train_params.dist_reg_coeficient = min(max(1 / args.coarse, 0.01), 0.12)  # train_model.py:124-125
+    model = getattr(models, cfg.nerf.type)(cfg)
+    sd_c = synthetic.make_state_dict(True, 11, 20.0)   # weight set B ("sharpened"), SURVEY.md 8d
+    sd_f = synthetic.make_state_dict(False, 12, 20.0)
+    model.coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    model.fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    model.to(device)
+    return model, cfg, sd_c, sd_f
+
+
+class KernelTimer:
+    """HIP-event timing of one kernel family on torch's current stream (the stream the C ABI launches on)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.active = False
+
+    def __call__(self, M, launch):
+        if not self.active:
+            return launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = launch()
+        e1.record()
+        self.pairs.append((M, e0, e1))
+        return out
+
+    def mean_ms(self, M):
+        ts = [a.elapsed_time(b) for m, a, b in self.pairs if m == M]
+        return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
+
+
+def cpu_baseline(args, cfg, sd_c, sd_f):
+    """The CPU oracle (a C port of the reference path, oracle/) on a bounded sample of the same workload."""
+    import oracle as O
+    from ddnerf_amd import synthetic
+
+    n = args.cpu_rays
+    threads = os.cpu_count() or 1
+    O.set_threads(threads)
+    ro, rd, rad, _ = synthetic.make_rays("blender", n, 1)
+    t_lin = torch.linspace(0.0, 1.0, args.coarse + 1).numpy()
+    u_det = torch.linspace(0.0, 0.9999, args.fine + 1).numpy()
+    rng = np.random.default_rng(0)
+    kw = dict(model="dd", nc=args.coarse, nf=args.fine, near=2.0, far=6.0, blender=True, pdf_padding=True, smooth=1.7,
+              dist_reg=float(cfg.train_params.dist_reg_coeficient), t_lin=t_lin, u_det=u_det,
+              noise0=rng.standard_normal((n, args.coarse)).astype(np.float32),
+              noise1=rng.standard_normal((n, args.fine)).astype(np.float32))
+    O.run_iter(ro[:16], rd[:16], rad[:16], sd_c, sd_f, **dict(kw, noise0=kw["noise0"][:16], noise1=kw["noise1"][:16]))
+    t0 = time.perf_counter()
+    O.run_iter(ro, rd, rad, sd_c, sd_f, **kw)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rays/s", "cores": O.get_threads(), "kind": "port",
+            "sample": "%d rays x (%d+%d) samples, render pass, C oracle with OpenMP, %.1f s" % (n, args.coarse, args.fine, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+
+        td.init_process_group("nccl", device_id=device)
+    from ddnerf_amd import ops, synthetic
+
+    model, cfg, sd_c, sd_f = build_model(args, device)
+    ro, rd, rad, tgt = (torch.from_numpy(x).to(device) for x in synthetic.make_rays("blender", args.rays, 1 + rank))
+    torch.manual_seed(1234 + rank)
+
+    timer = KernelTimer()
+    ops.MLP_LAUNCH_HOOK = timer
+
+    if args.mode == "render":
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                return model.run_iter(ro, rd, rad, mode="validation", rgb_target=tgt)
+    else:
+        from ddnerf_amd import train_step
+
+        stepper = train_step.TrainStepper(model, cfg, dist=dist)
+
+        def step():
+            return stepper.step(ro, rd, rad, tgt)
+
+    def fence():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer.active = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.active = False
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        M_fine = args.rays * args.fine
+        ms, launches = timer.mean_ms(M_fine)
+        roof = None
+        if ms:
+            ach = M_fine * FLOP_FINE / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "mlp_%s_fwd_kernel<fine> (%d samples/launch)" % (args.mlp, M_fine),
+                    "achieved": round(ach, 2), "peak": PEAK[args.mlp], "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK[args.mlp], 4), "traffic": None, "launch_ms": round(ms, 4),
+                    "launches_timed": launches}
+        line = {
+            "metric": "rays/sec (4096 rays x 128 samples, 8x256 MLP)",
+            "value": round(world * args.rays * args.steps / dt, 1), "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.mlp == "fp32" else "bf16 (f32 accumulate)", "data": "synthetic",
+            "config": {"workload": "config_blender.yml DDNerfModel, %d rays/GPU x (%d coarse + %d fine), run_iter %s pass"
+                                   % (args.rays, args.coarse, args.fine, args.mode),
+                       "rays_per_gpu": args.rays, "mode": args.mode, "weights": "seeded, fc_alpha x20",
+                       "parallelism": "dp%d (independent ray batches)" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f)
+        print(json.dumps(line), flush=True)
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,7 @@ SOURCES = {
     "rays_encode.hip": EXACT,
     "composite.hip": EXACT,
     "samplers.hip": EXACT,
+    "dp_loss.hip": EXACT,
     "mlp_f32.hip": [],
 }
 

@@ -1,0 +1,258 @@
+"""MI355X host-side mirror of the reference's `models.models` module surface.
+
+`GeneralMipNerfModel(cfg, backbone="MipNeRFModel")` and `DDNerfModel(cfg)` are selected by name exactly like
+the reference (`getattr(models, cfg.nerf.type)(cfg)`, train_model.py:70) and expose the same methods
+(`run_iter`, `to`, `train`, `eval`, `load_weights_from_checkpoint`), attributes (`coarse`, `fine`, live `cfg`)
+and output schema (reference models/models.py:9-184, 187-322).  The per-ray inner loop --
+encode, MLP, DD head, compositing, hierarchical sampling, dp-loss -- runs in the hand-written HIP kernels of
+libddnerf_hip.so; this file is control flow only and has no CPU fallback.
+
+Random tensors are drawn through `self.rng` in the reference's order (per ray chunk: rand for the first-cycle
+jitter, randn for the coarse compositing noise, rand for the resampling jitter, randn for the fine noise) so
+a replaying generator reproduces the reference bit for bit in the parity tests."""
+from __future__ import annotations
+
+import torch
+
+from . import base_architectures
+from . import functions as F
+from . import ops
+
+
+class TorchRng:
+    """Default random source: torch's generator of the device the rays live on."""
+
+    def rand(self, shape, device):
+        return torch.rand(shape, dtype=torch.float32, device=device)
+
+    def randn(self, shape, device):
+        return torch.randn(shape, dtype=torch.float32, device=device)
+
+
+_const_cache = {}
+
+
+def _host_const(kind, a, b, steps, device):
+    """torch.linspace / arange rows built on the CPU (the reference's CPU path) and cached on the device."""
+    key = (kind, float(a), float(b), int(steps), str(device))
+    t = _const_cache.get(key)
+    if t is None:
+        if kind == "linspace":
+            t = torch.linspace(a, b, steps, dtype=torch.float32)
+        else:  # arange(steps) * s, float32 semantics of `torch.arange(n) * python_float`
+            t = torch.arange(steps) * a
+        t = t.to(torch.float32).to(device)
+        _const_cache[key] = t
+    return t
+
+
+def get_minibatches(inputs, chunksize=1024 * 8):
+    """general_utils/nerf_helpers.py:19-24"""
+    return [inputs[i:i + chunksize] for i in range(0, inputs.shape[0], chunksize)]
+
+
+class GeneralMipNerfModel(torch.nn.Module):
+    """mip-NeRF: one shared MLP, two passes, `sample_pdf` resampling (models/models.py:9-184)."""
+
+    def __init__(self, cfg, backbone="MipNeRFModel"):
+        super().__init__()
+        self.coarse = getattr(base_architectures, backbone)(
+            hidden_size=cfg.nerf.coarse_hidden_size, max_ipe_deg=16, num_encoding_fn_dir=4, include_input_xyz=False,
+            include_input_dir=True, use_viewdirs=True)
+        self.fine = self.coarse
+        self.cfg = cfg
+        self.rng = TorchRng()
+        self._set_mlp_dtype()
+
+    def _set_mlp_dtype(self):
+        dt = self.cfg.nerf.get("mlp_dtype", "fp32") if hasattr(self.cfg.nerf, "get") else "fp32"
+        for net in {id(self.coarse): self.coarse, id(self.fine): self.fine}.values():
+            net.mlp_dtype = dt
+
+    # ---- public surface -----------------------------------------------------------------------------
+    def run_iter(self, ray_origins, ray_directions, ray_rad, mode="train", depth_analysis_validation=False,
+                 rgb_target=None):
+        """models/models.py:40-73"""
+        shape_rgb = ray_directions.shape
+        shape_depth = ray_directions.shape[:-1]
+        batches = self.get_rays_batches(ray_origins, ray_directions, ray_rad, mode)
+        if rgb_target is not None:
+            rgb_targets = get_minibatches(rgb_target.reshape(-1, 3), chunksize=getattr(self.cfg.nerf, mode).chunksize)
+        else:
+            rgb_targets = [None for _ in batches]
+        pred = [self.predict(b, mode, depth_analysis_validation, t) for b, t in zip(batches, rgb_targets)]
+        output = pred[0]
+        for i in range(1, len(pred)):
+            for j in range(len(output)):
+                for key in pred[i][j].keys():
+                    v = pred[i][j][key]
+                    if (v is not None) and (v is not False):
+                        output[j][key] = torch.cat((output[j][key], v), dim=0)
+        if mode == "validation" and not depth_analysis_validation:
+            for i in range(len(output)):
+                output[i]["rgb"] = output[i]["rgb"].view(shape_rgb)
+                for k in ("disp", "acc", "depth"):
+                    output[i][k] = output[i][k].view(shape_depth)
+                if output[i].get("corrected_disp_map") is not None:
+                    output[i]["corrected_disp_map"] = output[i]["corrected_disp_map"].view(shape_depth)
+        return output
+
+    def get_rays_batches(self, ray_origins, ray_directions, ray_rad, mode):
+        """models/models.py:144-162 (K0 pack kernel, then views of <= chunksize rays)"""
+        rays = ops.pack_rays(ray_origins, ray_directions, ray_rad, self.cfg.dataset.near, self.cfg.dataset.far)
+        return get_minibatches(rays, chunksize=getattr(self.cfg.nerf, mode).chunksize)
+
+    def to(self, device):
+        self.coarse.to(device)
+        self.fine.to(device)
+
+    def load_weights_from_checkpoint(self, checkpoint):
+        self.coarse.load_state_dict(checkpoint["model_1_state_dict"])
+        if self.cfg.nerf.type != "GeneralMipNerfModel":
+            self.fine.load_state_dict(checkpoint["model_2_state_dict"])
+
+    def train(self):
+        self.coarse.train()
+        self.fine.train()
+
+    def eval(self):
+        self.coarse.eval()
+        self.fine.eval()
+
+    # ---- pieces of predict ---------------------------------------------------------------------------
+    def _mode_cfg(self, mode):
+        return getattr(self.cfg.nerf, mode)
+
+    def _is_blender(self):
+        d = self.cfg.dataset
+        return str(d.type).lower() == "blender" or str(d.basedir).endswith("segmented")  # volume_rendering_utils.py:51
+
+    def _first_cycle(self, rays, mode):
+        """models/samplers.py:30-62"""
+        mc = self._mode_cfg(mode)
+        if self.cfg.dataset.get("combined_sampling_method", False):
+            raise NotImplementedError("dataset.combined_sampling_method is off in every shipped config and not built")
+        nc = mc.num_coarse
+        t_lin = _host_const("linspace", 0.0, 1.0, nc + 1, rays.device)
+        t_rand = self.rng.rand((rays.shape[0], nc + 1), rays.device) if mc.perturb else None
+        return ops.sample_first_cycle(rays, t_lin, t_rand, bool(mc.lindisp))
+
+    def _noise(self, n, S, mode, device):
+        std = self._mode_cfg(mode).radiance_field_noise_std
+        if std > 0.0:
+            return self.rng.randn((n, S), device) * std  # volume_rendering_utils.py:29-37
+        return None
+
+    def run_network(self, ray_batch, t_vals, network, mode):
+        """models/models.py:117-142: encode (K1) + fused MLP (K2); [n,S,4|6]"""
+        bf16 = network.mlp_dtype == "bf16"
+        shape = str(self.cfg.nerf.ray_shape)
+        if shape not in ("cone", "cylinder"):
+            raise AssertionError("ray_shape must be 'cone' or 'cylinder'")  # math_utils.py:28
+        feat = ops.encode(ray_batch, t_vals, cylinder=(shape == "cylinder"), bf16=bf16)
+        raw = F.mlp(feat, network)
+        return raw.reshape(t_vals.shape[0], t_vals.shape[1] - 1, raw.shape[-1])
+
+    def predict(self, ray_batch, mode, depth_analysis_validation, rgb_target=None):
+        """models/models.py:75-114"""
+        if depth_analysis_validation:
+            raise NotImplementedError("depth-analysis plots are debug visualisation, outside the hot path")
+        mc = self._mode_cfg(mode)
+        n = ray_batch.shape[0]
+        ret = {}
+        weights = t_vals = None
+        for i in range(2):
+            if i == 0:
+                t_vals = self._first_cycle(ray_batch, mode)
+            else:
+                ns = mc.num_fine + 1
+                det = (mc.perturb == 0.0)
+                if det:
+                    u_base, rnd = _host_const("linspace", 0.0, 1.0, ns, ray_batch.device), None
+                else:
+                    u_base = _host_const("arange", 1 / ns, 0.0, ns, ray_batch.device)
+                    rnd = self.rng.rand((n, ns), ray_batch.device)
+                t_vals = ops.sample_pdf(t_vals, weights.detach(), u_base, rnd, bool(self.cfg.train_params.pdf_padding))
+            raw = self.run_network(ray_batch, t_vals, self.coarse, mode)
+            c = F.composite(raw, t_vals, ray_batch, self._noise(n, t_vals.shape[1] - 1, mode, ray_batch.device), None,
+                            bool(mc.white_background), self._is_blender())
+            weights = c["weights"]
+            ret[i] = {"rgb": c["rgb_map"], "disp": c["disp"], "acc": c["acc"], "weights": weights, "depth": c["depth"]}
+        return ret
+
+
+class DDNerfModel(GeneralMipNerfModel):
+    """DDNeRF: coarse net with a depth-distribution head, separate fine net, truncated-Gaussian resampling and
+    the dp (KL) loss (models/models.py:187-322)."""
+
+    def __init__(self, cfg):
+        GeneralMipNerfModel.__init__(self, cfg, backbone="DepthMipNeRFModel")
+        try:
+            hidden_size_fine = cfg.nerf.fine_hidden_size
+        except (AttributeError, KeyError):
+            print("no nidden size params for fine model, set 256")
+            hidden_size_fine = 256
+        self.fine = base_architectures.MipNeRFModel(
+            hidden_size=hidden_size_fine, max_ipe_deg=16, num_encoding_fn_dir=4, include_input_xyz=False,
+            include_input_dir=True, use_viewdirs=True)
+        self._set_mlp_dtype()
+
+    def predict(self, ray_batch, mode, depth_analysis_validation, rgb_target=None):
+        """models/models.py:207-322"""
+        if depth_analysis_validation:
+            raise NotImplementedError("depth-analysis plots are debug visualisation, outside the hot path")
+        cfg, mc = self.cfg, self._mode_cfg(mode)
+        n, dev = ray_batch.shape[0], ray_batch.device
+        blender = self._is_blender()
+        ret = {}
+        model = self.coarse
+        for i in range(2):
+            if i == 1:
+                model = self.fine
+                mus = None
+            if i == 0:
+                t_vals = self._first_cycle(ray_batch, mode)
+            else:
+                ns = mc.num_fine + 1
+                det = (mc.perturb == 0.0)
+                if det:
+                    u_base, rnd = _host_const("linspace", 0.0, 0.9999, ns, dev), None
+                else:
+                    u_base = _host_const("arange", 1 / (ns - 1), 0.0, ns, dev)
+                    rnd = self.rng.rand((n, ns), dev)
+                # a fresh leaf in the reference (nn.Parameter): nothing flows back through the sampler
+                t_vals = ops.sample_pdf_mu_sigma(t_vals_0, weights_0.detach(), mus_0.detach(), head["ssig"].detach(),
+                                                 head["spart"].detach(), head["sleft"].detach(), u_base, rnd,
+                                                 cfg.dataset.near, cfg.dataset.far, bool(cfg.train_params.pdf_padding))
+            raw = self.run_network(ray_batch, t_vals, model, mode)
+            if i == 0:
+                head = F.dd_head(raw, cfg.train_params.gaussian_smooth_factor, cfg.train_params.dist_reg_coeficient)
+                mus, sigmas = head["mus"], head["sigmas"]
+                smoothed_sigmas = head["ssig"]
+                scal = head["scal"]
+                mus_loss, sig_loss, mus_reg, sig_reg = scal[0], scal[1], scal[2], scal[3]
+            c = F.composite(raw, t_vals, ray_batch, self._noise(n, t_vals.shape[1] - 1, mode, dev), mus,
+                            bool(mc.white_background), blender)
+            weights = c["weights"]
+            if i == 0:
+                t_vals_0, mus_0, sigmas_0, weights_0 = t_vals, mus, sigmas, weights
+            dp_loss = None
+            if i == 1:
+                dp = F.dp_loss(t_vals.detach(), t_vals_0.detach(), weights.detach(), weights_0, mus_0, sigmas_0,
+                               head["left"].detach(), head["part"].detach(), str(cfg.dataset.type).lower() == "blender")
+                dp_loss = (dp * (t_vals.shape[1] - 1) + mus_reg + sig_reg).unsqueeze(0)          # :287-289
+            if mus is not None:                                                                  # :292-295
+                pdf = weights / torch.sum(weights, dim=-1, keepdim=True)
+                keep = pdf > 0.1
+                mus_to_record = mus[keep]
+                sigmas_to_record = sigmas[keep]
+            # level 1 records the stale level-0 tensors under the level-0 mask, as the reference does (:297-300)
+            ret[i] = {"rgb": c["rgb_map"], "disp": c["disp"], "acc": c["acc"], "weights": weights, "depth": c["depth"],
+                      "mus": mus_to_record, "sigmas": sigmas_to_record, "dp_loss": dp_loss,
+                      "corrected_disp_map": c["cdisp"], "smoothed_sigmas": smoothed_sigmas[keep]}
+            if i == 0:
+                ret[i]["mus_loss"] = mus_loss.unsqueeze(0)
+                ret[i]["sig_loss"] = sig_loss.unsqueeze(0)
+                ret[i]["mus_reg"] = mus_reg.unsqueeze(0)
+                ret[i]["sig_reg"] = sig_reg.unsqueeze(0)
+        return ret

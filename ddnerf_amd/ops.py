@@ -9,6 +9,8 @@ import torch
 from . import _lib
 
 FEAT_LD = 128
+# optional instrumentation: callable(M, launch) -> launch(); bench.py installs a HIP-event timer here
+MLP_LAUNCH_HOOK = None
 
 
 def _ptr(t):
@@ -75,8 +77,15 @@ def mlp_f32_forward(feat, packed, depth_head):
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
     raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
-    _lib.check(_lib.lib().ddnerf_mlp_f32_forward(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), M, _stream()),
-               "ddnerf_mlp_f32_forward")
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_mlp_f32_forward(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), M, _stream()),
+                   "ddnerf_mlp_f32_forward")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
     return raw
 
 
@@ -137,3 +146,16 @@ def sample_pdf_mu_sigma(bins, weights, mus, sigmas, part, left, u_base, rnd, nea
                                                      _ptr(out), _ptr(ind), n, nc, ns, int(pdf_padding), _stream()),
                "ddnerf_sample_pdf_mu_sigma")
     return (out, ind) if want_ind else out
+
+
+def dp_loss_forward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender):
+    """models/dd_utils.py:6-78 -> 0-dim fp32 tensor (kl_div mean over kept rows; 0 if none kept)"""
+    t1, t0, w1, w0, mus0, sig0, left0, part0 = (_f32c(t, "dp_loss arg") for t in (t1, t0, w1, w0, mus0, sig0, left0, part0))
+    n, nc = w0.shape
+    nf = w1.shape[1]
+    loss = torch.empty((), dtype=torch.float32, device=w0.device)
+    ws = torch.empty(_lib.lib().ddnerf_dp_loss_workspace_bytes(n), dtype=torch.uint8, device=w0.device)
+    _lib.check(_lib.lib().ddnerf_dp_loss_forward(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0),
+                                                 _ptr(part0), n, nc, nf, int(blender), _ptr(loss), _ptr(ws), _stream()),
+               "ddnerf_dp_loss_forward")
+    return loss

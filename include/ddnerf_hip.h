@@ -110,6 +110,16 @@ int ddnerf_sample_pdf_mu_sigma(const float *bins, const float *weights, const fl
                                float near_, float far_, float *samples, int32_t *bins_ind, int n, int nc, int ns,
                                int pdf_padding, ddnerf_stream_t stream);
 
+/* a13  estimate_dp_loss  models/dd_utils.py:6-78 (forward value).
+ * t1 [n,nf+1], t0 [n,nc+1], w1 [n,nf] (fine weights), w0 [n,nc] (coarse weights), mus0/sig0/left0/part0 [n,nc].
+ * blender != 0 applies the row filter sum(w1) > 1e-10, including the reference's un-filtered left_tails_0
+ * gather (row r of the FILTERED set reads left0 row r).  loss[0] = kl_div(..., reduction='mean') over the kept
+ * rows, 0 when no row is kept.  workspace: ddnerf_dp_loss_workspace_bytes(n) bytes. */
+size_t ddnerf_dp_loss_workspace_bytes(int n);
+int ddnerf_dp_loss_forward(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,
+                           const float *sig0, const float *left0, const float *part0, int n, int nc, int nf,
+                           int blender, float *loss, void *workspace, ddnerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,3 +48,14 @@ def maxerr(a, b):
         return 0.0
     assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN pattern differs"
     return float(np.nanmax(np.abs(a - b))) if np.isfinite(a).any() else 0.0
+
+
+def relerr(a, b):
+    """max |a-b| / max(1, |b|): absolute below 1, relative above (disparities reach 1e10)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN pattern differs"
+    return float(np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
