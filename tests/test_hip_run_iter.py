@@ -94,7 +94,7 @@ def test_run_iter_forward_matches_reference(name):
         assert out[0]["dp_loss"] is None and out[1]["corrected_disp_map"] is None
         for k in ("mus", "sigmas", "smoothed_sigmas"):
             a, b = out[0][k].cpu().numpy(), g["o0_" + k]
-            assert a.shape == b.shape and np.abs(a - b).max() <= 5e-6, k
+            assert a.shape == b.shape and (a.size == 0 or np.abs(a - b).max() <= 5e-6), k
             assert np.array_equal(out[1][k].cpu().numpy(), a)        # stale level-0 record, like the reference
         assert relerr(out[0]["corrected_disp_map"].cpu().numpy(), g["o0_corrected_disp_map"]) <= 5e-6
         for k in ("mus_loss", "sig_loss", "mus_reg", "sig_reg"):
