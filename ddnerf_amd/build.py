@@ -20,6 +20,7 @@ SOURCES = {
     "samplers.hip": EXACT,
     "dp_loss.hip": EXACT,
     "mlp_f32.hip": [],
+    "mlp_bf16.hip": [],
 }
 
 

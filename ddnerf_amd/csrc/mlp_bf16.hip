@@ -1,0 +1,350 @@
+// K2 (bf16): the whole 8x256 MLP (models/base_architectures.py:40-61, 103-126) as ONE kernel on the bf16
+// matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- the north-star roofline kernel.
+//
+// Same transposed formulation as the fp32 kernel:  H_out^T[out, sample] = W[out, in] * H_in^T[in, sample]
+//   A operand = 32 out-rows x 16 in-features of W, read from LDS (ds_read_b128 per lane);
+//   B operand = 16 in-features x 32 samples of the previous layer's output.  A 32x32 fp32 accumulator tile has
+//               the sample on the lane and the feature on the register; converting registers 8s..8s+7 pairwise to
+//               bf16 gives the B fragment of k-step s with NO lane movement -- in a permuted k order
+//               (element j of lane half h = feature 16s + 8(j>>2) + 4h + (j&3)); W is packed in the same k
+//               order (per 16 columns the four quads are stored [0,2,1,3]), and so are the bf16 feature rows the
+//               encode kernel writes (include/ddnerf_hip.h, DDNERF "k-order").
+// Activations never leave registers.  A wave owns 32 samples: B file 64 VGPR (256 features as packed bf16) +
+// 128 accumulator registers; 8 waves (2 per SIMD) = 256 samples per workgroup share every LDS-staged weight
+// byte, and one wave's layer epilogue (bias, ReLU, bf16 pack: VALU) overlaps its SIMD partner's MFMAs.
+//
+// Weights: repacked once per update into the exact LDS image -- 32-row slices, row stride K+8 bf16 (the 16-byte
+// pad makes the b128 fragment reads bank-conflict free), grouped in STAGES of <= 66 KiB that are 1-KiB multiples --
+// stored in consumption order.  Stage s+1 is streamed global->LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
+// while stage s feeds the MFMAs; two stage buffers, one barrier per stage.
+#include <utility>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// ---- schedule -------------------------------------------------------------------------------------------
+// 11 packed layers as in the fp32 kernel: K (in) / NB (32-row out blocks):
+#define NL 11
+static constexpr int kK[NL] = {96, 256, 256, 256, 256, 352, 256, 256, 256, 288, 128};
+static constexpr int kNB[NL] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 5, 1};
+// slices per stage (a stage must fit one LDS buffer): K=256 -> 4 (66.5 KiB), K=352 -> 2, K=96 -> 8, K=288 -> 3+2, K=128 -> 1
+static constexpr int kSPS[NL] = {8, 4, 4, 4, 4, 2, 4, 4, 4, 3, 1};
+#define STAGE_BYTES_MAX (67 * 1024)
+
+// one slice = 32 rows of (K + 8) bf16, then the 32 fp32 biases of those rows
+__host__ __device__ constexpr int slice_bytes(int K) { return 32 * (2 * K + 16) + 128; }
+__host__ __device__ constexpr int round_kib(int b) { return (b + 1023) / 1024 * 1024; }
+// bytes of stage `st` (0-based) of layer l, padded to a 1-KiB multiple
+__host__ __device__ constexpr int stage_bytes(int l, int st) {
+    int first = st * kSPS[l];
+    int ns = kNB[l] - first < kSPS[l] ? kNB[l] - first : kSPS[l];
+    return round_kib(ns * slice_bytes(kK[l]));
+}
+__host__ __device__ constexpr int stages_of(int l) { return (kNB[l] + kSPS[l] - 1) / kSPS[l]; }
+
+struct PlanB {
+    int layer_off[NL];  // byte offset of the layer's first stage in the packed buffer
+    int w_src[13];
+    int b_src[13];
+    int total_bytes;
+};
+
+static PlanB make_plan_b(int depth_head) {
+    PlanB p;
+    static const int nout[13] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 1, 128, 3, 2};
+    static const int nin[13] = {96, 256, 256, 256, 256, 352, 256, 256, 256, 256, 283, 128, 128};
+    int off = 0;
+    for (int l = 0; l < 13; ++l) {
+        p.w_src[l] = off;
+        off += nout[l] * nin[l];
+        p.b_src[l] = off;
+        off += nout[l];
+        if (l == 11 && !depth_head) {
+            p.w_src[12] = p.b_src[12] = -1;
+            break;
+        }
+    }
+    off = 0;
+    for (int l = 0; l < NL; ++l) {
+        p.layer_off[l] = off;
+        for (int st = 0; st < stages_of(l); ++st) off += stage_bytes(l, st);
+    }
+    p.total_bytes = off;
+    return p;
+}
+
+DDN_EXPORT size_t ddnerf_mlp_bf16_packed_bytes(int depth_head) { return (size_t)make_plan_b(depth_head).total_bytes; }
+
+// same source mapping as the fp32 kernel (see mlp_f32.hip)
+__device__ __forceinline__ float srcw(const float *__restrict__ P, const PlanB &pl, int l, int o, int c) {
+    if (l <= 8) return P[pl.w_src[l] + o * kK[l] + c];
+    if (l == 9) {
+        if (o < 128) return c < 283 ? P[pl.w_src[10] + o * 283 + c] : 0.0f;
+        if (o == 128) return c < 256 ? P[pl.w_src[9] + c] : 0.0f;
+        return 0.0f;
+    }
+    if (o < 3) return P[pl.w_src[11] + o * 128 + c];
+    if ((o == 4 || o == 5) && pl.w_src[12] >= 0) return P[pl.w_src[12] + (o - 4) * 128 + c];
+    return 0.0f;
+}
+__device__ __forceinline__ float srcb(const float *__restrict__ P, const PlanB &pl, int l, int o) {
+    if (l <= 8) return P[pl.b_src[l] + o];
+    if (l == 9) return o < 128 ? P[pl.b_src[10] + o] : (o == 128 ? P[pl.b_src[9]] : 0.0f);
+    if (o < 3) return P[pl.b_src[11] + o];
+    if ((o == 4 || o == 5) && pl.b_src[12] >= 0) return P[pl.b_src[12] + (o - 4)];
+    return 0.0f;
+}
+
+// k-order: inside every 16 columns the quads are stored [0,2,1,3]
+__host__ __device__ __forceinline__ constexpr int korder(int p) {  // packed position -> original column (an involution)
+    return (p & ~15) | ((p & 3) + 4 * (((p >> 2) & 1) * 2 + ((p >> 3) & 1)));
+}
+
+__global__ void mlp_bf16_pack_kernel(const float *__restrict__ P, PlanB pl, unsigned short *__restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 16-bit word of the packed buffer
+    if (idx >= pl.total_bytes / 2) return;
+    int byte = idx * 2, l = NL - 1;
+    while (l > 0 && byte < pl.layer_off[l]) --l;
+    int rel = byte - pl.layer_off[l], st = 0;
+    while (rel >= stage_bytes(l, st)) {
+        rel -= stage_bytes(l, st);
+        ++st;
+    }
+    const int K = kK[l], rowb = 2 * K + 16;
+    const int sl = rel / slice_bytes(K);  // slice inside the stage
+    const int first = st * kSPS[l];
+    const int nsl = kNB[l] - first < kSPS[l] ? kNB[l] - first : kSPS[l];
+    unsigned short w = 0;
+    if (sl < nsl) {
+        int r2 = rel - sl * slice_bytes(K);
+        if (r2 < 32 * rowb) {
+            int row = r2 / rowb, col = (r2 % rowb) / 2;
+            float v = col < K ? srcw(P, pl, l, 32 * (first + sl) + row, korder(col)) : 0.0f;
+            __bf16 b = (__bf16)v;
+            w = __builtin_bit_cast(unsigned short, b);
+        } else {  // fp32 bias of row (r2 - 32*rowb)/4, written as two 16-bit halves
+            int bi = (r2 - 32 * rowb) / 4, half = ((r2 - 32 * rowb) % 4) / 2;
+            unsigned u = __builtin_bit_cast(unsigned, srcb(P, pl, l, 32 * (first + sl) + bi));
+            w = (unsigned short)(half ? (u >> 16) : (u & 0xffffu));
+        }
+    }
+    packed[idx] = w;
+}
+
+DDN_EXPORT int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
+    DDN_REQUIRE(params && packed, DDNERF_E_ARG);
+    DDN_REQUIRE(ddn_aligned(packed, 16), DDNERF_E_ALIGN);
+    PlanB pl = make_plan_b(depth_head);
+    int threads = pl.total_bytes / 2;
+    hipLaunchKernelGGL(mlp_bf16_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, pl,
+                       (unsigned short *)packed);
+    return ddn_launch_status();
+}
+
+// ---- fused forward ----------------------------------------------------------------------------------------
+#define WG_THREADS 512
+#define WG_SAMPLES 256
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// LDS-DMA of one stage: `bytes` (1-KiB multiple) from global `src` to LDS `dst`, 1 KiB per wave-instruction.
+__device__ __forceinline__ void dma_stage(const char *__restrict__ src, char *dst, int bytes, int wave, int lane) {
+    for (int off = wave * 1024; off < bytes; off += 8 * 1024)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(dst + off), 16, 0, 0);
+}
+
+// two floats -> one packed bf16 pair (one v_cvt_pk_bf16_f32)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b, bool relu) {
+    f32x2 v = {a, b};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);
+    if (relu) {  // ReLU on the bf16 bit patterns: signed 16-bit max with 0 (v_pk_max_i16)
+        const s16x2 z = {0, 0};
+        r = __builtin_bit_cast(bf16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, r), z));
+    }
+    return __builtin_bit_cast(unsigned, r);
+}
+// half of an accumulator tile (registers 8s..8s+7) -> the B fragment of k-step s of the next layer
+template <int S>
+__device__ __forceinline__ bf16x8 to_bfrag(const f32x16 &acc, bool relu) {
+    u32x4 w;
+    w[0] = pack_bf16(acc[8 * S + 0], acc[8 * S + 1], relu);
+    w[1] = pack_bf16(acc[8 * S + 2], acc[8 * S + 3], relu);
+    w[2] = pack_bf16(acc[8 * S + 4], acc[8 * S + 5], relu);
+    w[3] = pack_bf16(acc[8 * S + 6], acc[8 * S + 7], relu);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// B-operand source of k-step ks of a layer: KIND 0 first layer (xyz, X[0..5]); 1 hidden (H[ks]); 2 skip layer
+// (X[0..5] then H[0..15]); 3 dir layer (H[0..15] then X[6..7] = view dirs); 4 heads (H[0..7])
+template <int KIND, int KS>
+__device__ __forceinline__ const bf16x8 &bsrc(const bf16x8 (&H)[16], const bf16x8 (&X)[8]) {
+    if constexpr (KIND == 0) return X[KS];
+    else if constexpr (KIND == 2) {
+        if constexpr (KS < 6) return X[KS];
+        else return H[KS - 6];
+    } else if constexpr (KIND == 3) {
+        if constexpr (KS < 16) return H[KS];
+        else return X[6 + (KS - 16)];
+    } else return H[KS];
+}
+
+#define SG_MFMA 0x008
+#define SG_VALU 0x002
+#define SG_DSRD 0x100
+
+// One stage: NBLK 32-row slices out of LDS buffer `cur`.  Explicitly software-pipelined, in program order
+// (pinned with sched_group_barrier): A fragments are read DEPTH MFMAs ahead into a ring of DEPTH registers sets;
+// the bias tile of block b+1 (= its accumulator start value) is read during block b; the bf16 re-pack of a
+// finished tile (VALU) is placed behind the first MFMAs of the next block.
+template <int KIND, int K, int NBLK, int B0, int NCONV>
+__device__ __forceinline__ void stage_compute(const char *__restrict__ cur, const bf16x8 (&H)[16], const bf16x8 (&X)[8],
+                                              bf16x8 (&Hn)[16], f32x16 (&keep)[2], bool relu, int lane) {
+    constexpr int NKS = K / 16, P = NBLK * NKS, DEPTH = 4, ROWB = 2 * K + 16, SLB = slice_bytes(K);
+    const char *a_lane = cur + (lane & 31) * ROWB + 16 * (lane >> 5);
+    const char *b_lane = cur + 32 * ROWB + 16 * (lane >> 5);
+    bf16x8 ring[DEPTH];
+    f32x16 acc[2];
+    auto read_a = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        ring[p % DEPTH] = *(const bf16x8 *)(a_lane + (p / NKS) * SLB + 32 * (p % NKS));
+    };
+    auto read_bias = [&](auto bc, auto gc) {  // rows 8g + 4h + (0..3) of block b -> accumulator registers 4g..4g+3
+        constexpr int b = decltype(bc)::value, g = decltype(gc)::value;
+        const f32x4 v = *(const f32x4 *)(b_lane + b * SLB + 32 * g);
+        acc[b & 1][4 * g + 0] = v.x;
+        acc[b & 1][4 * g + 1] = v.y;
+        acc[b & 1][4 * g + 2] = v.z;
+        acc[b & 1][4 * g + 3] = v.w;
+    };
+    static_for<4>([&](auto g) { read_bias(std::integral_constant<int, 0>{}, g); });
+    static_for<(DEPTH < P ? DEPTH : P)>([&](auto p) { read_a(p); });
+    __builtin_amdgcn_sched_barrier(0);
+    // the order below IS the schedule: sched_barrier(0) after every step keeps hipcc from re-serialising it
+    static_for<P>([&](auto pc) {
+        constexpr int p = decltype(pc)::value, b = p / NKS, ks = p % NKS;
+        acc[b & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % DEPTH], bsrc<KIND, ks>(H, X), acc[b & 1], 0, 0, 0);
+        if constexpr (p + DEPTH < P) read_a(std::integral_constant<int, p + DEPTH>{});
+        if constexpr (b + 1 < NBLK && ks >= NKS - 5 && ks < NKS - 1)  // next block's bias, one piece per step
+            read_bias(std::integral_constant<int, b + 1>{}, std::integral_constant<int, ks - (NKS - 5)>{});
+        if constexpr (b > 0 && ks >= 1 && ks <= 4) {  // re-pack the previous tile behind this block's first MFMAs
+            constexpr int pb = b - 1, q = ks - 1;     // quarter q: accumulator registers 4q..4q+3 -> one packed pair x2
+            if constexpr (B0 + pb < NCONV) {
+                u32x4 w = __builtin_bit_cast(u32x4, Hn[2 * (B0 + pb) + q / 2]);
+                w[2 * (q & 1) + 0] = pack_bf16(acc[pb & 1][4 * q + 0], acc[pb & 1][4 * q + 1], relu);
+                w[2 * (q & 1) + 1] = pack_bf16(acc[pb & 1][4 * q + 2], acc[pb & 1][4 * q + 3], relu);
+                Hn[2 * (B0 + pb) + q / 2] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    constexpr int lb = NBLK - 1;  // the stage's last tile is re-packed right away
+    if constexpr (B0 + lb < NCONV) {
+        Hn[2 * (B0 + lb)] = to_bfrag<0>(acc[lb & 1], relu);
+        Hn[2 * (B0 + lb) + 1] = to_bfrag<1>(acc[lb & 1], relu);
+    }
+    keep[0] = acc[lb & 1];                         // the layer's last tile (heads: rgb / mu,sigma rows)
+    if constexpr (NBLK > 1) keep[1] = acc[(lb - 1) & 1];
+}
+
+// One layer = its stages.  On entry the layer's first stage is in flight (or landed) in LDS buffer PAR.
+// NEXT = layer whose first stage is prefetched during this layer's last stage (-1: none).
+template <int L, int KIND, int NEXT, int PAR, int NCONV>
+__device__ __forceinline__ void layer(const char *__restrict__ &wp, char *lds, const bf16x8 (&H)[16],
+                                      const bf16x8 (&X)[8], bf16x8 (&Hn)[16], f32x16 (&keep)[2], bool relu, int wave,
+                                      int lane) {
+    constexpr int K = kK[L], NST = stages_of(L);
+    static_for<NST>([&](auto stc) {
+        constexpr int st = decltype(stc)::value;
+        constexpr int first = st * kSPS[L];
+        constexpr int nblk = kNB[L] - first < kSPS[L] ? kNB[L] - first : kSPS[L];
+        char *cur = lds + ((PAR + st) & 1) * STAGE_BYTES_MAX;
+        char *nxt = lds + ((PAR + st + 1) & 1) * STAGE_BYTES_MAX;
+        __syncthreads();  // stage `st` has landed (the compiler drains the DMA here) and the other buffer is free
+        wp += stage_bytes(L, st);
+        if constexpr (st + 1 < NST) dma_stage(wp, nxt, stage_bytes(L, st + 1), wave, lane);
+        else if constexpr (NEXT >= 0) dma_stage(wp, nxt, stage_bytes(NEXT >= 0 ? NEXT : 0, 0), wave, lane);
+        stage_compute<KIND, K, nblk, first, NCONV>(cur, H, X, Hn, keep, relu, lane);
+    });
+}
+
+template <bool DEPTH_HEAD>
+__global__ __launch_bounds__(WG_THREADS, 2) void mlp_bf16_fwd_kernel(const unsigned short *__restrict__ feat,
+                                                                     const char *__restrict__ packed,
+                                                                     float *__restrict__ raw, long M) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES_MAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const long m = (long)blockIdx.x * WG_SAMPLES + wave * 32 + j;
+    const bool valid = m < M;
+    const unsigned short *frow = feat + (size_t)(valid ? m : M - 1) * DDNERF_FEAT_LD;
+
+    bf16x8 HA[16], HB[16], X[8];
+    f32x16 keep[2];
+    const char *wp = packed;
+    dma_stage(wp, lds, stage_bytes(0, 0), wave, lane);
+    // features (bf16, k-order): lane half h takes the second 16 bytes of every 16-column group
+#pragma unroll
+    for (int g = 0; g < 8; ++g) X[g] = *(const bf16x8 *)(frow + 16 * g + 8 * h);
+
+    // parity of the LDS buffer holding a layer's first stage: L0 has 1 stage (buffer 0), every later layer has an
+    // even number of stages and starts in buffer 1
+    layer<0, 0, 1, 0, 8>(wp, lds, HA, X, HA, keep, true, wave, lane);    // 96 -> 256            (H unused: KIND 0)
+    layer<1, 1, 2, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);
+    layer<2, 1, 3, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
+    layer<3, 1, 4, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);
+    layer<4, 1, 5, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
+    layer<5, 2, 6, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);    // cat(xyz, h) 352 -> 256, 4 stages
+    layer<6, 1, 7, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
+    layer<7, 1, 8, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);
+    layer<8, 1, 9, 1, 8>(wp, lds, HB, X, HA, keep, false, wave, lane);   // fc_feat: no activation
+    layer<9, 3, 10, 1, 4>(wp, lds, HA, X, HB, keep, true, wave, lane);   // dir layer (128, ReLU) + alpha row
+    const float alpha = keep[0][0];                                      // row 128 = block 4, register 0, lane half 0
+    layer<10, 4, -1, 1, 0>(wp, lds, HB, X, HA, keep, false, wave, lane);  // heads
+    const f32x16 &o = keep[0];
+
+    if (valid) {
+        if (DEPTH_HEAD) {
+            float *op = raw + (size_t)m * 6;
+            if (h == 0) {
+                *(float2 *)(op) = make_float2(o[0], o[1]);
+                *(float2 *)(op + 2) = make_float2(o[2], alpha);
+            } else {
+                *(float2 *)(op + 4) = make_float2(o[0], o[1]);  // rows 4, 5 = raw mu, raw sigma
+            }
+        } else if (h == 0) {
+            *(f32x4 *)(raw + (size_t)m * 4) = f32x4{o[0], o[1], o[2], alpha};
+        }
+    }
+}
+
+DDN_EXPORT int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M,
+                                       ddnerf_stream_t stream) {
+    DDN_REQUIRE(feat && packed && raw, DDNERF_E_ARG);
+    DDN_REQUIRE(M > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16), DDNERF_E_ALIGN);
+    dim3 grid((unsigned)((M + WG_SAMPLES - 1) / WG_SAMPLES));
+    if (depth_head)
+        hipLaunchKernelGGL(mlp_bf16_fwd_kernel<true>, grid, dim3(WG_THREADS), 0, (hipStream_t)stream,
+                           (const unsigned short *)feat, (const char *)packed, raw, M);
+    else
+        hipLaunchKernelGGL(mlp_bf16_fwd_kernel<false>, grid, dim3(WG_THREADS), 0, (hipStream_t)stream,
+                           (const unsigned short *)feat, (const char *)packed, raw, M);
+    return ddn_launch_status();
+}

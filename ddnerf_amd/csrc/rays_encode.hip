@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
         for (int e = tid; e < ENC_SPB * DDNERF_FEAT_LD / 2; e += 256) {
             int ls = e / (DDNERF_FEAT_LD / 2), c = (e % (DDNERF_FEAT_LD / 2)) * 2;
             if (m0 + ls < M) {
-                unsigned v = (unsigned)f32_to_bf16(row[ls][c]) | ((unsigned)f32_to_bf16(row[ls][c + 1]) << 16);
+                // bf16 rows are stored in MFMA k-order: inside every 16 columns the quads are [0,2,1,3]
+                const int cs = (c & ~15) | ((c & 3) + 4 * (((c >> 2) & 1) * 2 + ((c >> 3) & 1)));
+                unsigned v = (unsigned)f32_to_bf16(row[ls][cs]) | ((unsigned)f32_to_bf16(row[ls][cs + 1]) << 16);
                 *(unsigned *)(feat + (m0 + ls) * DDNERF_FEAT_LD + c) = v;
             }
         }

@@ -89,6 +89,36 @@ def mlp_f32_forward(feat, packed, depth_head):
     return raw
 
 
+def mlp_bf16_pack(params_flat, depth_head):
+    params_flat = _f32c(params_flat, "params")
+    nbytes = _lib.lib().ddnerf_mlp_bf16_packed_bytes(int(depth_head))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=params_flat.device)
+    _lib.check(_lib.lib().ddnerf_mlp_bf16_pack(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()),
+               "ddnerf_mlp_bf16_pack")
+    return packed
+
+
+def mlp_bf16_forward(feat, packed, depth_head):
+    """bf16-MFMA MLP: feat bf16 [M,128] in k-order (as written by encode(bf16=True)) -> raw fp32 [M,4|6]"""
+    if not (feat.is_cuda and feat.dtype == torch.bfloat16 and feat.is_contiguous()):
+        raise _lib.DDNerfHipError("mlp_bf16_forward wants a contiguous bf16 GPU feature tensor")
+    M = feat.shape[0]
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_mlp_bf16_forward(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), M, _stream()),
+                   "ddnerf_mlp_bf16_forward")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw
+
+
+K_ORDER = [(p & ~15) | ((p & 3) + 4 * (((p >> 2) & 1) * 2 + ((p >> 3) & 1))) for p in range(FEAT_LD)]
+
+
 def dd_head(raw6, smooth, dist_reg):
     """models/models.py:242-260, 266-273.  raw6 [n,nc,6]"""
     raw6 = _f32c(raw6, "raw6")

@@ -63,7 +63,8 @@ int ddnerf_sample_first_cycle(const float *rays, const float *t_lin, const float
 
 /* a3+a4+a5  cast_rays -> integrated_pos_enc, positional_encoding(view dirs), concat
  * general_utils/math_utils.py:7-166, general_utils/nerf_helpers.py:127-171, models/models.py:124-133
- * t_vals [n,S+1] -> feat [n*S,128].  ray_shape: 0 cone, 1 cylinder.  feat_dtype: 0 fp32, 1 bf16. */
+ * t_vals [n,S+1] -> feat [n*S,128].  ray_shape: 0 cone, 1 cylinder.  feat_dtype: 0 fp32 (natural column
+ * order), 1 bf16 (columns in MFMA k-order, see ddnerf_mlp_bf16_forward). */
 int ddnerf_encode(const float *rays, const float *t_vals, void *feat, int n, int S, int ray_shape, int feat_dtype,
                   ddnerf_stream_t stream);
 
@@ -75,6 +76,15 @@ size_t ddnerf_mlp_f32_packed_floats(int depth_head);
 int ddnerf_mlp_f32_pack(const float *params, int depth_head, float *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_f32_forward(const float *feat, const float *packed, int depth_head, float *raw, long M,
                            ddnerf_stream_t stream);
+
+/* bf16-MFMA variant of the same network (bf16 operands, fp32 accumulation, fp32 biases and outputs).
+ * feat: bf16 [M,128] as written by ddnerf_encode(feat_dtype=1), i.e. in MFMA "k-order": inside every 16
+ * columns the four quads are stored [0,2,1,3] (the order in which an accumulator tile re-enters the next
+ * layer's matrix instruction as its B operand). */
+size_t ddnerf_mlp_bf16_packed_bytes(int depth_head);
+int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M,
+                            ddnerf_stream_t stream);
 
 /* a8  DD head, inline in DDNerfModel.predict  models/models.py:242-260, 266-273
  * raw6 [n,nc,6] -> mus, sigmas, left_tail, part_inside (raw sigma) and smoothed sigma/left/part, all [n,nc];

@@ -48,7 +48,14 @@ def test_pack_rays_encode_mlp(ops, golden, name):
     assert maxerr(feat[:, 96:123].reshape(g["rays"].shape[0], -1, 27)[:, 0], g["dirs"]) <= 2.4e-7
     # bf16 feature variant = round-to-nearest-even of the fp32 one
     fb = ops.encode(dev(g["rays"]), dev(g["t_vals"]), cylinder=cyl, bf16=True)
-    assert torch.equal(fb.cpu(), torch.from_numpy(feat).to(torch.bfloat16))
+    assert torch.equal(fb.cpu(), torch.from_numpy(feat[:, ops.K_ORDER]).to(torch.bfloat16))   # columns in MFMA k-order
+    # bf16-MFMA MLP: bf16 operands, fp32 accumulate -- its own tolerance tier
+    for depth, seed, key in ((True, 11, "raw6"), (False, 12, "raw4")):
+        sd = synthetic.make_state_dict(depth, seed)
+        packed = ops.mlp_bf16_pack(dev(flat_params(sd, depth)), depth)
+        raw = host(ops.mlp_bf16_forward(fb, packed, depth))
+        ref = g[key].reshape(raw.shape)
+        assert maxerr(raw, ref) <= 4e-3, key
     # fused fp32 MLP on the golden features
     for depth, seed, key in ((True, 11, "raw6"), (False, 12, "raw4")):
         sd = synthetic.make_state_dict(depth, seed)
@@ -70,6 +77,38 @@ def test_mlp_f32_ragged_and_large(ops):
         raw = host(ops.mlp_f32_forward(dev(feat), packed, depth))
         ref = O.mlp_forward(feat, sd, depth)
         assert maxerr(raw, ref) <= 2e-6 * max(1.0, np.abs(ref).max()), (M, depth)
+
+
+def test_mlp_bf16_ragged_vs_bf16_emulation(ops):
+    """bf16 kernel against an fp64 evaluation of the SAME bf16-rounded weights/features/activations:
+    isolates kernel bugs (wrong k-permutation, tile maps) from the expected bf16 quantisation error."""
+    rng = np.random.default_rng(6)
+
+    def bf(x):
+        return torch.from_numpy(np.asarray(x, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+    for M, depth in ((1, True), (255, False), (257, True), (1500, False)):
+        feat = np.zeros((M, 128), np.float32)
+        feat[:, :123] = rng.uniform(-1, 1, (M, 123)).astype(np.float32)
+        sd = synthetic.make_state_dict(depth, 4, 1.0)
+        W = {k: (bf(v) if k.endswith("weight") else v.astype(np.float64)) for k, v in sd.items()}
+        x = bf(feat)
+        xyz, dirs = x[:, :96], x[:, 96:123]
+        h = xyz
+        for i in range(8):
+            inp = np.concatenate([xyz, h], 1) if i == 5 else h
+            h = bf(np.maximum(inp @ W["layers_xyz.%d.weight" % i].T + W["layers_xyz.%d.bias" % i], 0))
+        ft = bf(h @ W["fc_feat.weight"].T + W["fc_feat.bias"])
+        alpha = ft @ W["fc_alpha.weight"].T + W["fc_alpha.bias"]
+        hd = bf(np.maximum(np.concatenate([ft, dirs], 1) @ W["layers_dir.0.weight"].T + W["layers_dir.0.bias"], 0))
+        outs = [hd @ W["fc_rgb.weight"].T + W["fc_rgb.bias"], alpha]
+        if depth:
+            outs.append(hd @ W["fc_mu_sigma.weight"].T + W["fc_mu_sigma.bias"])
+        ref = np.concatenate(outs, 1)
+        fb = torch.from_numpy(np.ascontiguousarray(feat[:, ops.K_ORDER])).to(torch.bfloat16).cuda().contiguous()
+        packed = ops.mlp_bf16_pack(dev(flat_params(sd, depth)), depth)
+        raw = host(ops.mlp_bf16_forward(fb, packed, depth))
+        assert maxerr(raw, ref) <= 2e-3 * max(1.0, np.abs(ref).max()), (M, depth)   # rounding-boundary flips only
 
 
 @pytest.mark.parametrize("tag", ["lin", "disp", "ndc"])
