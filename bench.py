@@ -91,7 +91,8 @@ def cpu_baseline(args, cfg, sd_c, sd_f):
     from ddnerf_amd import synthetic
 
     n = args.cpu_rays
-    threads = os.cpu_count() or 1
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(threads, int(os.environ.get("DDNERF_CPU_THREADS", "64")))
     O.set_threads(threads)
     ro, rd, rad, _ = synthetic.make_rays("blender", n, 1)
     t_lin = torch.linspace(0.0, 1.0, args.coarse + 1).numpy()

@@ -242,14 +242,17 @@ class DDNerfModel(GeneralMipNerfModel):
                                head["left"].detach(), head["part"].detach(), str(cfg.dataset.type).lower() == "blender")
                 dp_loss = (dp * (t_vals.shape[1] - 1) + mus_reg + sig_reg).unsqueeze(0)          # :287-289
             if mus is not None:                                                                  # :292-295
-                pdf = weights / torch.sum(weights, dim=-1, keepdim=True)
-                keep = pdf > 0.1
-                mus_to_record = mus[keep]
-                sigmas_to_record = sigmas[keep]
+                # one stream compaction (a single host sync) serves the three logging-only records
+                with torch.no_grad():
+                    pdf = weights / torch.sum(weights, dim=-1, keepdim=True)
+                    sel = torch.nonzero((pdf > 0.1).reshape(-1)).squeeze(1)
+                mus_to_record = mus.reshape(-1)[sel]
+                sigmas_to_record = sigmas.reshape(-1)[sel]
+                ssig_to_record = smoothed_sigmas.reshape(-1)[sel]
             # level 1 records the stale level-0 tensors under the level-0 mask, as the reference does (:297-300)
             ret[i] = {"rgb": c["rgb_map"], "disp": c["disp"], "acc": c["acc"], "weights": weights, "depth": c["depth"],
                       "mus": mus_to_record, "sigmas": sigmas_to_record, "dp_loss": dp_loss,
-                      "corrected_disp_map": c["cdisp"], "smoothed_sigmas": smoothed_sigmas[keep]}
+                      "corrected_disp_map": c["cdisp"], "smoothed_sigmas": ssig_to_record}
             if i == 0:
                 ret[i]["mus_loss"] = mus_loss.unsqueeze(0)
                 ret[i]["sig_loss"] = sig_loss.unsqueeze(0)

@@ -1,0 +1,81 @@
+"""CPU-side checks of the boundary: the C-ABI library loads without a GPU and exports exactly the symbols
+include/ddnerf_hip.h declares; argument validation happens on the host before any launch."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ddnerf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddnerf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ddnerf_amd import _lib
+
+    lib = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libddnerf_hip.so does not export %s" % n
+    assert sorted(_lib._SIGS) == names, "ctypes signature table and header disagree"
+    assert lib.ddnerf_abi_version() >= 1
+
+
+def test_argument_validation_without_gpu():
+    from ddnerf_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.ddnerf_pack_rays(None, None, None, 2.0, 6.0, None, 16, None) == -1      # DDNERF_E_ARG
+    assert lib.ddnerf_encode(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 4, 7, 0, None) == -2
+    assert lib.ddnerf_encode(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(20), 4, 4, 0, 0, None) == -3
+    assert lib.ddnerf_sample_pdf(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None,
+                                 ctypes.c_void_p(16), 4, 1, 9, 1, None) == -1                 # nc == 1 rejected
+    assert b"aligned" in lib.ddnerf_error_string(-3)
+    assert lib.ddnerf_mlp_f32_packed_floats(0) > 600000 and lib.ddnerf_mlp_bf16_packed_bytes(1) > 1200000
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+
+    from ddnerf_amd import _lib, ops
+
+    with pytest.raises(_lib.DDNerfHipError):
+        ops.pack_rays(torch.zeros(4, 3), torch.ones(4, 3), torch.ones(4, 1), 2.0, 6.0)
+
+
+def test_model_surface_and_checkpoint_keys():
+    """constructor / attribute surface of the drop-in models and state-dict compatibility"""
+    import torch
+
+    from ddnerf_amd import synthetic
+    from ddnerf_amd.cfgnode import CfgNode
+    from models import models
+
+    cfg = CfgNode.load(os.path.join(ROOT, "configs", "config_blender.yml"))
+    m = getattr(models, cfg.nerf.type)(cfg)
+    assert m.coarse is not m.fine and m.cfg is cfg
+    assert [k for k in m.coarse.state_dict()] == [n + s for n, _, _ in synthetic.layer_table(True) for s in (".weight", ".bias")]
+    assert sum(p.numel() for p in m.coarse.parameters()) == 612998 and sum(p.numel() for p in m.fine.parameters()) == 612740
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(True, 3).items()}
+    m.load_weights_from_checkpoint({"model_1_state_dict": sd, "model_2_state_dict": m.fine.state_dict()})
+    flat = m.coarse.flat_params()
+    assert flat.shape == (612998,) and torch.equal(flat[:24576].view(256, 96), sd["layers_xyz.0.weight"])
+    # optimiser updates write through to the flat buffer (parameters are views of it)
+    opt = torch.optim.Adam(m.coarse.parameters(), lr=1e-3)
+    for p in m.coarse.parameters():
+        p.grad = torch.ones_like(p)
+    before = flat.clone()
+    opt.step()
+    assert not torch.equal(m.coarse.flat_params(), before) and m.coarse.flat_params().data_ptr() == flat.data_ptr()
+    cfg2 = CfgNode.load(os.path.join(ROOT, "configs", "config_blender_mipnerf.yml"))
+    g = getattr(models, cfg2.nerf.type)(cfg2)
+    assert g.fine is g.coarse and g.coarse.depth_head is False
+    for name in ("run_iter", "to", "train", "eval", "load_weights_from_checkpoint", "predict", "run_network",
+                 "get_rays_batches"):
+        assert callable(getattr(m, name))
