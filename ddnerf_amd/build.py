@@ -20,6 +20,7 @@ SOURCES = {
     "samplers.hip": EXACT,
     "dp_loss.hip": EXACT,
     "mlp_f32.hip": [],
+    "mlp_f32_train.hip": [],
     "mlp_bf16.hip": [],
 }
 
@@ -29,7 +30,7 @@ def _stale(target, deps):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_f32_common.h"), os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)

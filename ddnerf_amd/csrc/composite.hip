@@ -212,3 +212,145 @@ DDN_EXPORT int ddnerf_dd_head(const float *raw6, int n, int nc, float smooth, fl
                        scal);
     return ddn_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// K3b  backward of volume_render_radiance_field w.r.t. the raw network outputs.
+// Upstream gradients that exist in the reference's graph: d(rgb_map) from the MSE losses and
+// d(weights) from the dp loss (coarse level; NULL otherwise).  disp / acc / depth / corrected_disp are not
+// differentiated (nothing in the reference's losses reads them).
+//   c_jk = sigmoid(r_jk)*1.002 - 0.001;  sigma_j = softplus(r_j3 + noise - 1);  a_j = 1 - exp(-sigma_j d_j)
+//   T_j = prod_{i<j} (1 - a_i + 1e-10);  w_j = a_j T_j;  rgb_map_k = sum_j w_j c_jk (+ 1 - sum_j w_j if white)
+//   dL/dw_j  = sum_k G_k c_jk + gw_j - (white ? sum_k G_k : 0)
+//   dL/da_j  = T_j dL/dw_j - (sum_{i>j} dL/dw_i w_i) / (1 - a_j + 1e-10)
+//   dL/dr_j3 = dL/da_j * d_j (1 - a_j) * sigmoid(r_j3 + noise - 1);   dL/dr_jk = G_k w_j * 1.002 s(1-s)
+// One wave per ray; the suffix sum is a wave-level reverse scan.  g_raw has row stride ldr; columns >= 4 are
+// written as zero (so the DD-head gradient can simply be added).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float *__restrict__ raw, int ldr, const float *__restrict__ t_vals, const float *__restrict__ rays,
+    const float *__restrict__ noise, int n, int S, int flags, const float *__restrict__ g_rgb_map,
+    const float *__restrict__ g_weights, float *__restrict__ g_raw) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * COMP_WAVES + wave;
+    const bool live = ray < n;
+    float *alpha = smem + (size_t)wave * 4 * S;  // [S]
+    float *trans = alpha + S;                    // [S] exclusive transmittance
+    float *dw = trans + S;                       // [S] dL/dw
+    float *suf = dw + S;                         // [S] dL/dw_j * w_j, then its exclusive suffix sum
+    const bool white = flags & DDNERF_COMP_WHITE_BKGD;
+    const size_t r0 = live ? ray : 0;
+    const float *t = t_vals + r0 * (S + 1);
+    const float *d = rays + 12 * r0 + 3;
+    const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float G0 = g_rgb_map[3 * r0], G1 = g_rgb_map[3 * r0 + 1], G2 = g_rgb_map[3 * r0 + 2];
+    const float Gsum = white ? (G0 + G1) + G2 : 0.0f;
+
+    if (live)
+        for (int j = lane; j < S; j += 64) {
+            const size_t m = r0 * S + j;
+            float dens = raw[m * ldr + 3] + (noise ? noise[m] : 0.0f);
+            float sig = ddn_softplus(dens - 1.0f);
+            float a = 1.0f - expf(-sig * ((t[j + 1] - t[j]) * dn));
+            alpha[j] = a;
+            trans[j] = 1.0f - a + 1e-10f;
+        }
+    __syncthreads();
+    if (live && lane == 0) {  // same transmittance arithmetic as the forward kernel
+        double p = 1.0;
+        for (int j = 0; j < S; ++j) {
+            float x = trans[j];
+            trans[j] = (float)p;
+            p *= (double)x;
+        }
+    }
+    __syncthreads();
+    if (live)
+        for (int j = lane; j < S; j += 64) {
+            const size_t m = r0 * S + j;
+            const float *r = raw + m * ldr;
+            float w = alpha[j] * trans[j];
+            float s0 = ddn_sigmoid(r[0]), s1 = ddn_sigmoid(r[1]), s2 = ddn_sigmoid(r[2]);
+            float c0 = s0 * 1.002f - 0.001f, c1 = s1 * 1.002f - 0.001f, c2 = s2 * 1.002f - 0.001f;
+            float dLdw = (G0 * c0 + G1 * c1 + G2 * c2) - Gsum + (g_weights ? g_weights[m] : 0.0f);
+            dw[j] = dLdw;
+            suf[j] = dLdw * w;
+            float *g = g_raw + m * ldr;
+            g[0] = G0 * w * 1.002f * s0 * (1.0f - s0);
+            g[1] = G1 * w * 1.002f * s1 * (1.0f - s1);
+            g[2] = G2 * w * 1.002f * s2 * (1.0f - s2);
+            for (int k = 4; k < ldr; ++k) g[k] = 0.0f;
+        }
+    __syncthreads();
+    // exclusive suffix sum of suf[] by the wave: chunks of 64 from the back, carry across chunks
+    float carry = 0.0f;
+    const int nchunk = (S + 63) / 64;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        int j = c * 64 + lane;
+        float v = (live && j < S) ? suf[j] : 0.0f;
+        float inc = v;  // inclusive suffix within the chunk
+        for (int o = 1; o < 64; o <<= 1) {
+            float up = __shfl_down(inc, o);
+            if (lane + o < 64) inc += up;
+        }
+        float excl = inc - v + carry;
+        if (live && j < S) suf[j] = excl;
+        carry += __shfl(inc, 0);
+    }
+    __syncthreads();
+    if (live)
+        for (int j = lane; j < S; j += 64) {
+            const size_t m = r0 * S + j;
+            float a = alpha[j], om = 1.0f - a + 1e-10f;
+            float dLda = trans[j] * dw[j] - suf[j] / om;
+            float dens = raw[m * ldr + 3] + (noise ? noise[m] : 0.0f);
+            float delta = (t[j + 1] - t[j]) * dn;
+            g_raw[m * ldr + 3] = dLda * delta * (1.0f - a) * ddn_sigmoid(dens - 1.0f);
+        }
+}
+
+DDN_EXPORT int ddnerf_composite_backward(const float *raw, int ldr, const float *t_vals, const float *rays,
+                                         const float *noise, int n, int S, int flags, const float *g_rgb_map,
+                                         const float *g_weights, float *g_raw, ddnerf_stream_t stream) {
+    DDN_REQUIRE(raw && t_vals && rays && g_rgb_map && g_raw, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ldr >= 4, DDNERF_E_RANGE);
+    size_t lds = (size_t)COMP_WAVES * 4 * S * sizeof(float);
+    DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds,
+                       (hipStream_t)stream, raw, ldr, t_vals, rays, noise, n, S, flags, g_rgb_map, g_weights, g_raw);
+    return ddn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward of the DD head w.r.t. raw[..., 4:6]  (models/models.py:245-252)
+//   mus = sigmoid(rm); sigmas = sigmoid(rs) + 1e-3; mus_loss = sum rm^2 / n; sig_loss = sum rs^2 / n;
+//   mus_reg = c mus_loss; sig_reg = c sig_loss.     g_scal = upstream grads of {mus_loss, sig_loss, mus_reg, sig_reg}
+// Adds into g_raw6[..., 4] and [..., 5] (the compositing backward has written zeros there).
+// ---------------------------------------------------------------------------------------------------
+__global__ void dd_head_bwd_kernel(const float *__restrict__ raw6, size_t count, int n, float dist_reg,
+                                   const float *__restrict__ g_mus, const float *__restrict__ g_sigmas,
+                                   const float *__restrict__ g_scal, float *__restrict__ g_raw6) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float rm = raw6[6 * i + 4], rs = raw6[6 * i + 5];
+    float mu = ddn_sigmoid(rm), sg = ddn_sigmoid(rs);
+    float cm = 0.0f, cs = 0.0f;
+    if (g_scal) {
+        cm = (g_scal[0] + dist_reg * g_scal[2]) * 2.0f / (float)n;
+        cs = (g_scal[1] + dist_reg * g_scal[3]) * 2.0f / (float)n;
+    }
+    g_raw6[6 * i + 4] += (g_mus ? g_mus[i] * mu * (1.0f - mu) : 0.0f) + cm * rm;
+    g_raw6[6 * i + 5] += (g_sigmas ? g_sigmas[i] * sg * (1.0f - sg) : 0.0f) + cs * rs;
+}
+
+DDN_EXPORT int ddnerf_dd_head_backward(const float *raw6, int n, int nc, float dist_reg, const float *g_mus,
+                                       const float *g_sigmas, const float *g_scal, float *g_raw6,
+                                       ddnerf_stream_t stream) {
+    DDN_REQUIRE(raw6 && g_raw6, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    size_t count = (size_t)n * nc;
+    hipLaunchKernelGGL(dd_head_bwd_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw6,
+                       count, n, dist_reg, g_mus, g_sigmas, g_scal, g_raw6);
+    return ddn_launch_status();
+}

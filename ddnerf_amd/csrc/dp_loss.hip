@@ -167,3 +167,208 @@ DDN_EXPORT int ddnerf_dp_loss_forward(const float *t1, const float *t0, const fl
     hipLaunchKernelGGL(dpl_finish_kernel, dim3(1), dim3(64), 0, st, rowsum, total, nf, loss);
     return ddn_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// K5b  backward of estimate_dp_loss w.r.t. (w0, mus0, sig0) -- the only differentiable inputs at the call site
+// (models/models.py:287-288: every other argument is .detach()ed).  The discrete choices (row filter, bin
+// indices k / ki, the two clamps) are constants of the backward pass, exactly as in autograd.
+// Recomputes the forward quantities of the row, then walks the chain backwards.  Scatter-adds into bins are
+// done bin-parallel (lane j sums the samples m whose bin is j, in ascending m: k_m is monotone because t1 is
+// sorted) so the result is order-fixed -- no atomics.
+// Rows that were filtered out receive zero gradient.
+// ---------------------------------------------------------------------------------------------------
+#define DPLB_WORDS(nc, nf) (4 * (nc) + 2 + 11 * ((nf) + 1))
+
+__global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
+    const float *__restrict__ t1, const float *__restrict__ t0, const float *__restrict__ w1,
+    const float *__restrict__ w0, const float *__restrict__ mus0, const float *__restrict__ sig0,
+    const float *__restrict__ left0, const float *__restrict__ part0, int n, int nc, int nf,
+    const int *__restrict__ keep, const int *__restrict__ rank, const int *__restrict__ total,
+    const float *__restrict__ g_loss, float *__restrict__ g_w0, float *__restrict__ g_mus, float *__restrict__ g_sig) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * DPL_WAVES + wave;
+    const bool inrange = row < n;
+    const bool live = inrange && keep[inrange ? row : 0];
+    const size_t i = inrange ? row : 0;
+    const int r = live ? rank[i] : 0;
+    const int nf1 = nf + 1;
+    float *p0 = smem + (size_t)wave * DPLB_WORDS(nc, nf);  // [nc]
+    float *cdf = p0 + nc;                                  // [nc+1]
+    float *gp0 = cdf + nc + 1;                             // [nc]    d/d p0
+    float *gcdf = gp0 + nc;                                // [nc+1]  pass flag of min(1,.), then d/d cdf
+    float *p1 = gcdf + nc + 1;                             // [nf+1]
+    float *est = p1 + nf1;                                 // [nf+1]  e_m after the >1 clamp
+    float *ge = est + nf1;                                 // [nf+1]  d/d e_m
+    float *cA = ge + nf1;                                  // [nf+1]  d e_m / d p0[ki]
+    float *cMu = cA + nf1;                                 // [nf+1]  d e_m / d mu[ki]
+    float *cSg = cMu + nf1;                                // [nf+1]  d e_m / d sg[ki]
+    float *dq = cSg + nf1;                                 // [nf+1]  d_m + eps, then d L / d d_m
+    int *kk = (int *)(dq + nf1);                           // [nf+1]  k_m
+    int *kki = kk + nf1;                                   // [nf+1]  ki_m
+    int *eclamp = kki + nf1;                               // [nf+1]  e_m was clamped to 1
+    int *dpos = eclamp + nf1;                              // [nf+1]  d_m was not clamped to 0
+    const float eps = 1e-12f;
+    const float *T1 = t1 + i * nf1, *T0 = t0 + i * (nc + 1);
+    const float *lt = left0 + (size_t)r * nc;  // misaligned on purpose, like the forward
+    const float *pt = part0 + i * nc, *mu = mus0 + i * nc, *sg = sig0 + i * nc;
+
+    if (inrange && !live)  // filtered row: zero gradient
+        for (int j = lane; j < nc; j += 64) {
+            g_w0[i * nc + j] = 0.0f;
+            g_mus[i * nc + j] = 0.0f;
+            g_sig[i * nc + j] = 0.0f;
+        }
+    if (live) {
+        for (int j = lane; j < nc; j += 64) p0[j] = w0[i * nc + j] + eps;
+        for (int j = lane; j < nf; j += 64) p1[j] = w1[i * nf + j] + eps;
+    }
+    __syncthreads();
+    const float s0 = ddn_aten_sum_wave(p0, nc, lane);
+    const float s1 = ddn_aten_sum_wave(p1, nf, lane);
+    if (live) {
+        for (int j = lane; j < nc; j += 64) p0[j] = p0[j] / s0;
+        for (int j = lane; j < nf; j += 64) p1[j] = p1[j] / s1;
+    }
+    __syncthreads();
+    if (live && lane == 0) {
+        double a = 0.0;
+        cdf[0] = 0.0f;
+        gcdf[0] = 0.0f;
+        for (int j = 0; j < nc - 1; ++j) {
+            a += (double)p0[j];
+            float c = (float)a;
+            cdf[j + 1] = fminf(1.0f, c);
+            gcdf[j + 1] = c < 1.0f ? 1.0f : 0.0f;
+        }
+        cdf[nc] = 1.0f;
+        gcdf[nc] = 0.0f;
+    }
+    __syncthreads();
+    if (live)
+        for (int m = lane; m <= nf; m += 64) {
+            const float tm = T1[m];
+            int lo = 0, hi = nc + 1;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (tm > T0[mid]) lo = mid + 1;
+                else hi = mid;
+            }
+            int k = lo > 0 ? lo - 1 : 0, ki = k;
+            while (ki > 0 && cdf[ki - 1] == cdf[k]) --ki;
+            if (ki > nc - 1) ki = nc - 1;
+            float seclen = T0[ki + 1] - T0[ki];
+            float mr = T0[ki] + mu[ki] * seclen, sr = sg[ki] * seclen;
+            float x = (tm - mr) / sr;
+            float a = (ddn_norm_cdf(x) - lt[ki]) / pt[ki];
+            float e = cdf[k] + a * p0[ki];
+            int cl = e > 1.0f;
+            est[m] = cl ? 1.0f : e;
+            eclamp[m] = cl;
+            kk[m] = k;
+            kki[m] = ki;
+            float dedx = (p0[ki] / pt[ki]) * (0.3989422804f * expf(-0.5f * x * x));  // d e / d x
+            cA[m] = a;
+            cMu[m] = dedx * (-1.0f / sr) * seclen;   // x = (t - mr)/sr, mr = T0 + mu*seclen
+            cSg[m] = dedx * (-x / sr) * seclen;      // sr = sg*seclen
+        }
+    __syncthreads();
+    if (live)
+        for (int m = lane; m < nf; m += 64) {
+            float dlt = est[m + 1] - est[m];
+            int pos = !(dlt < 0.0f);
+            dq[m] = (pos ? dlt : 0.0f) + eps;
+            dpos[m] = pos;
+        }
+    __syncthreads();
+    const float se = ddn_aten_sum_wave(dq, nf, lane);
+    float p1sum = 0.0f;
+    if (live)
+        for (int m = lane; m < nf; m += 64) p1sum += p1[m];
+    for (int o = 32; o > 0; o >>= 1) p1sum += __shfl_xor(p1sum, o);
+    const float gscale = live ? g_loss[0] / ((float)(*total) * (float)nf) : 0.0f;
+    __syncthreads();
+    if (live)
+        for (int m = lane; m < nf; m += 64) {  // l = sum_m xlogy(p,p) - p log q,  q = (d+eps)/se
+            float q = dq[m] / se;
+            dq[m] = dpos[m] ? gscale * (p1sum - p1[m] / q) / se : 0.0f;
+        }
+    __syncthreads();
+    if (live)
+        for (int m = lane; m <= nf; m += 64) {
+            float g = 0.0f;
+            if (m > 0) g += dq[m - 1];
+            if (m < nf) g -= dq[m];
+            ge[m] = eclamp[m] ? 0.0f : g;
+        }
+    __syncthreads();
+    if (live)
+        for (int j = lane; j <= nc; j += 64) {  // d/d cdf[j] = sum over the (contiguous) m with k_m == j
+            int lo = 0, hi = nf1;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (kk[mid] < j) lo = mid + 1;
+                else hi = mid;
+            }
+            float acc = 0.0f;
+            for (int m = lo; m <= nf && kk[m] == j; ++m) acc += ge[m];
+            gcdf[j] = acc * gcdf[j];  // zero for cdf[0], cdf[nc] and the clamped prefixes
+        }
+    __syncthreads();
+    if (live && lane == 0) {  // cdf[k] = sum_{j<k} p0[j]  ->  d/d p0[j] += sum_{k>j} gcdf[k]
+        float run = 0.0f;
+        for (int j = nc - 1; j >= 0; --j) {
+            run += gcdf[j + 1];
+            gp0[j] = run;
+        }
+    }
+    __syncthreads();
+    if (live)
+        for (int j = lane; j < nc; j += 64) {  // per-bin sums over the (contiguous) m with ki_m == j
+            int lo = 0, hi = nf1;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (kki[mid] < j) lo = mid + 1;
+                else hi = mid;
+            }
+            float a = 0.0f, b = 0.0f, c = 0.0f;
+            for (int m = lo; m <= nf && kki[m] == j; ++m) {
+                a += ge[m] * cA[m];
+                b += ge[m] * cMu[m];
+                c += ge[m] * cSg[m];
+            }
+            gp0[j] += a;
+            g_mus[i * nc + j] = b;
+            g_sig[i * nc + j] = c;
+        }
+    __syncthreads();
+    float dot = 0.0f;  // p0 = (w0+eps)/s0  ->  g_w0_j = (gp0_j - sum_i gp0_i p0_i) / s0
+    if (live)
+        for (int j = lane; j < nc; j += 64) dot += gp0[j] * p0[j];
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (live)
+        for (int j = lane; j < nc; j += 64) g_w0[i * nc + j] = (gp0[j] - dot) / s0;
+}
+
+DDN_EXPORT int ddnerf_dp_loss_backward(const float *t1, const float *t0, const float *w1, const float *w0,
+                                       const float *mus0, const float *sig0, const float *left0, const float *part0,
+                                       int n, int nc, int nf, int blender, const float *g_loss, float *g_w0,
+                                       float *g_mus, float *g_sig, void *workspace, ddnerf_stream_t stream) {
+    DDN_REQUIRE(t1 && t0 && w1 && w0 && mus0 && sig0 && left0 && part0 && g_loss && g_w0 && g_mus && g_sig && workspace,
+                DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0 && nf > 0, DDNERF_E_ARG);
+    int *keep = (int *)workspace, *rank = keep + n;
+    float *rowsum = (float *)(rank + n);
+    int *total = (int *)(rowsum + n);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((n + DPL_WAVES - 1) / DPL_WAVES);
+    // keep / rank / total are recomputed (cheap) so the backward does not depend on the forward's workspace
+    hipLaunchKernelGGL(dpl_keep_kernel, grid, dim3(256), (size_t)DPL_WAVES * nf * sizeof(float), st, w1, n, nf, blender,
+                       keep);
+    hipLaunchKernelGGL(dpl_scan_kernel, dim3(1), dim3(1024), 0, st, keep, n, rank, total);
+    size_t lds = (size_t)DPL_WAVES * DPLB_WORDS(nc, nf) * 4;
+    DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
+    hipLaunchKernelGGL(dpl_rows_bwd_kernel, grid, dim3(256), lds, st, t1, t0, w1, w0, mus0, sig0, left0, part0, n, nc, nf,
+                       keep, rank, total, g_loss, g_w0, g_mus, g_sig);
+    return ddn_launch_status();
+}

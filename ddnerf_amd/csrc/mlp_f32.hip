@@ -21,10 +21,7 @@
 // the 16-byte pad makes the b128 fragment reads bank-conflict free), stored in consumption order, so staging
 // is a linear copy.  Slices are double-buffered: slice s+1 is fetched into registers while slice s feeds the
 // MFMAs, written to the other LDS buffer afterwards, one barrier per slice.
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "mlp_f32_common.h"
 
 // ---- layer schedule -------------------------------------------------------------------------------
 // kind: 0 first layer (K=96 from xyz features)   1 hidden (K=256)   2 skip layer (K=352 = xyz96 + hidden256)
@@ -33,7 +30,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NLAYERS 11
 static constexpr int kLayerK[NLAYERS] = {96, 256, 256, 256, 256, 352, 256, 256, 256, 288, 128};
 static constexpr int kLayerNB[NLAYERS] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 5, 1};
-#define MAX_SLICE_FLOATS (32 * (352 + 4))
 
 struct PackPlan {
     int slice_off[NLAYERS];  // float offset of the layer's first slice in the packed buffer
@@ -117,90 +113,6 @@ DDN_EXPORT int ddnerf_mlp_f32_pack(const float *params, int depth_head, float *p
     hipLaunchKernelGGL(mlp_f32_pack_kernel, dim3((pl.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, pl,
                        packed);
     return ddn_launch_status();
-}
-
-// ---- fused forward ----------------------------------------------------------------------------------
-// B-operand register file of a wave: Breg[0..7] hidden activations, Breg[8..10] xyz features (96),
-// Breg[11] view-dir features (27 + 5 zeros).
-template <int KIND>
-__device__ __forceinline__ constexpr int bsel(int q) {
-    return KIND == 0 ? 8 + q / 4
-         : KIND == 1 ? q / 4
-         : KIND == 2 ? (q < 12 ? 8 + q / 4 : (q - 12) / 4)
-         : KIND == 3 ? (q < 32 ? q / 4 : 11)
-                     : q / 4;
-}
-
-// one 32-row slice: acc(32 out-features x 32 samples) += W_slice * B.
-// One wave per SIMD means nothing else hides the LDS latency: the A fragments are read two chunks
-// (8 MFMAs = 512 cycles) ahead of their use.
-template <int KIND, int K>
-__device__ __forceinline__ void slice_mfma(const float *__restrict__ buf, const f32x16 (&Breg)[12], f32x16 &acc,
-                                           int lane) {
-    constexpr int NQ = K / 8;
-    const float *a_row = buf + (lane & 31) * (K + 4) + 4 * (lane >> 5);
-    f32x4 a[NQ];
-    a[0] = *(const f32x4 *)(a_row);
-    a[1] = *(const f32x4 *)(a_row + 8);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (q + 2 < NQ) a[q + 2] = *(const f32x4 *)(a_row + 8 * (q + 2));
-        // pin the emitted order: 4 MFMAs, then the DS read that runs two chunks ahead (cdna guide T19)
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        const int blk = bsel<KIND>(q);
-        const int g = (KIND == 2 && q >= 12) ? (q - 12) % 4 : q % 4;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, Breg[blk][4 * g + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, Breg[blk][4 * g + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, Breg[blk][4 * g + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, Breg[blk][4 * g + 3], acc, 0, 0, 0);
-    }
-}
-
-__device__ __forceinline__ f32x16 bias_tile(const float *__restrict__ bias32, int h) {
-    f32x16 v;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *(const f32x4 *)(bias32 + 8 * g + 4 * h);
-        v[4 * g + 0] = b.x;
-        v[4 * g + 1] = b.y;
-        v[4 * g + 2] = b.z;
-        v[4 * g + 3] = b.w;
-    }
-    return v;
-}
-
-__device__ __forceinline__ f32x16 relu16(f32x16 v) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
-    return v;
-}
-
-// One slice step: fetch the NEXT slice (PF_N4 float4 pieces, 0 = nothing to fetch) into registers, multiply the
-// current one out of LDS, then park the fetched slice in the other LDS buffer; one barrier.
-template <int KIND, int K, int PF_N4>
-__device__ __forceinline__ void slice_step(const float *__restrict__ next_src, const float *__restrict__ bias32,
-                                           const float *cur, float *nxt, const f32x16 (&Breg)[12], f32x16 &acc,
-                                           int tid, int lane) {
-    constexpr int ROUNDS = (PF_N4 + 255) / 256;
-    f32x4 pf[ROUNDS > 0 ? ROUNDS : 1];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        int i4 = r * 256 + tid;
-        if (i4 > PF_N4 - 1) i4 = PF_N4 - 1;  // tail lanes re-read the last piece; their copy is not stored
-        pf[r] = *(const f32x4 *)(next_src + 4 * (size_t)i4);
-    }
-    acc = bias_tile(bias32, lane >> 5);
-    __builtin_amdgcn_sched_barrier(0);  // keep the fetch ABOVE the MFMA block: its latency hides under it
-    slice_mfma<KIND, K>(cur, Breg, acc, lane);
-    __builtin_amdgcn_sched_barrier(0);  // and the LDS commit BELOW it
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int i4 = r * 256 + tid;
-        if ((r + 1) * 256 <= PF_N4 || i4 < PF_N4) *(f32x4 *)(nxt + 4 * i4) = pf[r];
-    }
-    __syncthreads();
 }
 
 // One layer: NB slices.  `wp` walks the packed buffer (slices are stored in consumption order); while slice s

@@ -1,0 +1,110 @@
+// Shared device helpers of the fp32 fused-MLP kernels (forward, training forward, backward-data).
+// See mlp_f32.hip for the formulation (transposed layers, activations chained through the accumulator layout).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MAX_SLICE_FLOATS (32 * (352 + 4))
+
+// ---- fused forward ----------------------------------------------------------------------------------
+// B-operand register file of a wave: Breg[0..7] hidden activations, Breg[8..10] xyz features (96),
+// Breg[11] view-dir features (27 + 5 zeros).  Backward: Breg[0..7] deltas, Breg[8] the d(raw) tile.
+template <int KIND>
+__device__ __forceinline__ constexpr int bsel(int q) {
+    return KIND == 0 ? 8 + q / 4
+         : KIND == 1 ? q / 4
+         : KIND == 2 ? (q < 12 ? 8 + q / 4 : (q - 12) / 4)
+         : KIND == 3 ? (q < 32 ? q / 4 : 11)
+         : KIND == 10 ? 8                          // backward D0: the 32-row tile of d(raw)
+         : KIND == 11 ? (q < 16 ? q / 4 : 8)       // backward D1: d(dir hidden) blocks 0..3, then d(raw) (alpha row)
+                     : q / 4;
+}
+
+// one 32-row slice: acc(32 out-features x 32 samples) += W_slice * B.
+// One wave per SIMD means nothing else hides the LDS latency: the A fragments are read two chunks
+// (8 MFMAs = 512 cycles) ahead of their use.
+template <int KIND, int K>
+__device__ __forceinline__ void slice_mfma(const float *__restrict__ buf, const f32x16 (&Breg)[12], f32x16 &acc,
+                                           int lane) {
+    constexpr int NQ = K / 8;
+    const float *a_row = buf + (lane & 31) * (K + 4) + 4 * (lane >> 5);
+    f32x4 a[NQ];
+    a[0] = *(const f32x4 *)(a_row);
+    a[1] = *(const f32x4 *)(a_row + 8);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 2 < NQ) a[q + 2] = *(const f32x4 *)(a_row + 8 * (q + 2));
+        // pin the emitted order: 4 MFMAs, then the DS read that runs two chunks ahead (cdna guide T19)
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        const int blk = bsel<KIND>(q);
+        const int g = (KIND == 2 && q >= 12) ? (q - 12) % 4 : q % 4;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, Breg[blk][4 * g + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, Breg[blk][4 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, Breg[blk][4 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, Breg[blk][4 * g + 3], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ f32x16 bias_tile(const float *__restrict__ bias32, int h) {
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *(const f32x4 *)(bias32 + 8 * g + 4 * h);
+        v[4 * g + 0] = b.x;
+        v[4 * g + 1] = b.y;
+        v[4 * g + 2] = b.z;
+        v[4 * g + 3] = b.w;
+    }
+    return v;
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+    return v;
+}
+
+// One slice step: fetch the NEXT slice (PF_N4 float4 pieces, 0 = nothing to fetch) into registers, multiply the
+// current one out of LDS, then park the fetched slice in the other LDS buffer; one barrier.
+//   init(acc)  -- accumulator start value (bias tile / zero) and any loads whose latency should hide under the MFMAs
+//   post(acc)  -- runs after the slice's MFMAs (activation, stores of activations / deltas)
+template <int KIND, int K, int PF_N4, class Init, class Post>
+__device__ __forceinline__ void slice_step_hooks(const float *__restrict__ next_src, const float *cur, float *nxt,
+                                                 const f32x16 (&Breg)[12], f32x16 &acc, int tid, int lane, Init &&init,
+                                                 Post &&post) {
+    constexpr int ROUNDS = (PF_N4 + 255) / 256;
+    f32x4 pf[ROUNDS > 0 ? ROUNDS : 1];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        int i4 = r * 256 + tid;
+        if (i4 > PF_N4 - 1) i4 = PF_N4 - 1;  // tail lanes re-read the last piece; their copy is not stored
+        pf[r] = *(const f32x4 *)(next_src + 4 * (size_t)i4);
+    }
+    init(acc);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetches ABOVE the MFMA block: their latency hides under it
+    slice_mfma<KIND, K>(cur, Breg, acc, lane);
+    __builtin_amdgcn_sched_barrier(0);  // and the LDS commit BELOW it
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int i4 = r * 256 + tid;
+        if ((r + 1) * 256 <= PF_N4 || i4 < PF_N4) *(f32x4 *)(nxt + 4 * i4) = pf[r];
+    }
+    post(acc);
+    __syncthreads();
+}
+
+template <int KIND, int K, int PF_N4>
+__device__ __forceinline__ void slice_step(const float *__restrict__ next_src, const float *__restrict__ bias32,
+                                           const float *cur, float *nxt, const f32x16 (&Breg)[12], f32x16 &acc,
+                                           int tid, int lane) {
+    slice_step_hooks<KIND, K, PF_N4>(
+        next_src, cur, nxt, Breg, acc, tid, lane, [&](f32x16 &a) { a = bias_tile(bias32, lane >> 5); },
+        [](f32x16 &) {});
+}
+
+// row of accumulator register r inside a 32-row tile, for lane half h
+__device__ __forceinline__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

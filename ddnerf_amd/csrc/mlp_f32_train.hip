@@ -1,0 +1,378 @@
+// K2 training kernels (fp32): the forward that also records the activations, and the fused backward-data pass.
+//
+// Gradient structure: the MLP needs parameter gradients only -- no gradient w.r.t. its 123 input
+// features.  The work is split the MI355X way:
+//   * forward_train: the forward kernel of mlp_f32.hip that additionally stores every layer's output TRANSPOSED,
+//     acts[row = feature][col = sample]: in the accumulator layout a register holds one feature for 32 consecutive
+//     samples per lane half, so each store instruction writes two full 128-byte row segments.
+//   * backward_data: ONE fused kernel chains d(raw) back through all layers exactly like the forward chains
+//     activations -- delta_l^T = (W_{l+1}^T delta_{l+1}^T) * relu'(h_l), the accumulator tile of one step is the B
+//     operand of the next, deltas never leave registers between layers -- and stores every delta transposed too.
+//   * weight gradients dW_l = delta_l^T (h_{l-1}^T)^T are then plain GEMMs over the sample axis on the two stored
+//     [feature][sample] matrices (both operands K-contiguous): handed to the BLAS library by the host (ops.py),
+//     as are the bias gradients (row sums).
+// Row map of `acts` and `deltas` (ld = samples rounded up to 128):
+//   rows 256*l .. 256*l+255 : layers_xyz.l output (post-ReLU) / its pre-activation gradient,   l = 0..7
+//   rows 2048 .. 2303       : fc_feat output (no activation)  / its gradient
+//   rows 2304 .. 2431       : layers_dir.0 output (post-ReLU) / its pre-activation gradient
+#include "mlp_f32_common.h"
+
+#define ACT_ROWS 2432
+#define ROW_FEAT 2048
+#define ROW_DIR 2304
+
+// ---- packed images ------------------------------------------------------------------------------------------
+// forward plan (identical to mlp_f32.hip)
+#define NLAYERS 11
+static constexpr int kLayerK[NLAYERS] = {96, 256, 256, 256, 256, 352, 256, 256, 256, 288, 128};
+static constexpr int kLayerNB[NLAYERS] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 5, 1};
+// backward plan: step d -> (K = rows of the incoming delta, NB = 32-row blocks of the outgoing delta)
+//   d0: heads^T          K=32  (d raw tile)            -> d(dir hidden) 128 rows
+//   d1: [dir|alpha]^T    K=160 (d dir hidden + d raw)  -> d(feat)       256 rows
+//   d2: fc_feat^T        K=256                         -> d(h7)
+//   d3..d9: layers_xyz.{7..1}^T (layer 5: its hidden columns only)      -> d(h6) .. d(h0)
+#define NBSTEPS 10
+static constexpr int kBK[NBSTEPS] = {32, 160, 256, 256, 256, 256, 256, 256, 256, 256};
+static constexpr int kBNB[NBSTEPS] = {4, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+
+struct PlanT {
+    int step_off[NBSTEPS];  // float offset of the step's first slice
+    int w_src[13];
+    int total;
+};
+
+static PlanT make_plan_t(int depth_head) {
+    PlanT p;
+    static const int nout[13] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 1, 128, 3, 2};
+    static const int nin[13] = {96, 256, 256, 256, 256, 352, 256, 256, 256, 256, 283, 128, 128};
+    int off = 0;
+    for (int l = 0; l < 13; ++l) {
+        p.w_src[l] = off;
+        off += nout[l] * nin[l] + nout[l];
+        if (l == 11 && !depth_head) {
+            p.w_src[12] = -1;
+            break;
+        }
+    }
+    off = 0;
+    for (int d = 0; d < NBSTEPS; ++d) {
+        p.step_off[d] = off;
+        off += kBNB[d] * 32 * (kBK[d] + 4);
+    }
+    p.total = off;
+    return p;
+}
+
+DDN_EXPORT size_t ddnerf_mlp_f32_packed_t_floats(int depth_head) { return (size_t)make_plan_t(depth_head).total; }
+DDN_EXPORT size_t ddnerf_mlp_act_rows(void) { return ACT_ROWS; }
+
+// A^T element of backward step d: row c (feature of the outgoing delta), column o (row of the incoming delta)
+__device__ __forceinline__ float src_wt(const float *__restrict__ P, const PlanT &pl, int d, int c, int o) {
+    if (d == 0) {  // heads: incoming rows = raw columns (0..2 rgb, 3 alpha [not an input of this step], 4,5 mu,sigma)
+        if (o < 3) return P[pl.w_src[11] + o * 128 + c];
+        if ((o == 4 || o == 5) && pl.w_src[12] >= 0) return P[pl.w_src[12] + (o - 4) * 128 + c];
+        return 0.0f;
+    }
+    if (d == 1) {  // d(feat)[c] = sum_o W_dir[o][c] d(dir)[o]  +  W_alpha[c] d(raw)[3]
+        if (o < 128) return P[pl.w_src[10] + o * 283 + c];
+        if (o == 128 + 3) return P[pl.w_src[9] + c];
+        return 0.0f;
+    }
+    if (d == 2) return P[pl.w_src[8] + o * 256 + c];  // fc_feat
+    const int l = 10 - d;                              // d3 -> layers_xyz.7 ... d9 -> layers_xyz.1
+    if (l == 5) return P[pl.w_src[5] + o * 352 + 96 + c];
+    return P[pl.w_src[l] + o * 256 + c];
+}
+
+__global__ void mlp_f32_pack_t_kernel(const float *__restrict__ P, PlanT pl, float *__restrict__ packed) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pl.total) return;
+    int d = NBSTEPS - 1;
+    while (d > 0 && idx < pl.step_off[d]) --d;
+    const int ld = kBK[d] + 4, local = idx - pl.step_off[d];
+    const int c = local / ld, o = local % ld;
+    packed[idx] = o < kBK[d] ? src_wt(P, pl, d, c, o) : 0.0f;
+}
+
+DDN_EXPORT int ddnerf_mlp_f32_pack_t(const float *params, int depth_head, float *packed_t, ddnerf_stream_t stream) {
+    DDN_REQUIRE(params && packed_t, DDNERF_E_ARG);
+    DDN_REQUIRE(ddn_aligned(packed_t, 16), DDNERF_E_ALIGN);
+    PlanT pl = make_plan_t(depth_head);
+    hipLaunchKernelGGL(mlp_f32_pack_t_kernel, dim3((pl.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, pl,
+                       packed_t);
+    return ddn_launch_status();
+}
+
+// ---- shared: store / load one accumulator tile in the transposed [feature][sample] matrices -------------------
+__device__ __forceinline__ void store_tile_t(float *__restrict__ mat, size_t ld, int row0, size_t col, int h,
+                                             const f32x16 &v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mat[(size_t)(row0 + tile_row(r, h)) * ld + col] = v[r];
+}
+__device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, size_t ld, int row0, size_t col, int h) {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = mat[(size_t)(row0 + tile_row(r, h)) * ld + col];
+    return v;
+}
+
+template <int DST, int B0, int NBLK>
+__device__ __forceinline__ void load_features(const float *__restrict__ frow, int h, f32x16 (&Breg)[12]) {
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *(const f32x4 *)(frow + 32 * (B0 + b) + 8 * g + 4 * h);
+            Breg[DST + b][4 * g + 0] = v.x;
+            Breg[DST + b][4 * g + 1] = v.y;
+            Breg[DST + b][4 * g + 2] = v.z;
+            Breg[DST + b][4 * g + 3] = v.w;
+        }
+    }
+}
+
+// ---- forward that records activations -----------------------------------------------------------------------
+// One layer: as in mlp_f32.hip, plus: ReLU applied per tile and the tile stored to acts rows [ROW0 + 32 b ...].
+template <int KIND, int K, int NB, int NEXT_K, int PAR, bool RELU, int NSTORE>
+__device__ __forceinline__ void layer_fwd_train(const float *__restrict__ &wp, const float *__restrict__ bias, float *lds,
+                                                const f32x16 (&Breg)[12], f32x16 (&out)[8], float *__restrict__ acts,
+                                                size_t ld, int row0, size_t col, int tid, int lane) {
+    constexpr int N4 = 8 * (K + 4);
+    constexpr int NEXT_N4 = NEXT_K > 0 ? 8 * (NEXT_K + 4) : 0;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float *cur = lds + ((PAR + b) & 1) * MAX_SLICE_FLOATS;
+        float *nxt = lds + ((PAR + b + 1) & 1) * MAX_SLICE_FLOATS;
+        wp += 4 * N4;
+        auto init = [&](f32x16 &a) { a = bias_tile(bias + 32 * b, h); };
+        auto post = [&](f32x16 &a) {
+            if (b < NSTORE) {
+                if (RELU) a = relu16(a);
+                store_tile_t(acts, ld, row0 + 32 * b, col, h, a);
+            }
+        };
+        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+    }
+}
+
+struct FwdOffsets {
+    int bias_off[NLAYERS];
+};
+
+template <bool DEPTH>
+__global__ __launch_bounds__(256, 1) void mlp_f32_fwd_train_kernel(const float *__restrict__ feat,
+                                                                   const float *__restrict__ packed, FwdOffsets fo,
+                                                                   float *__restrict__ raw, float *__restrict__ acts,
+                                                                   long M, long ld) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MAX_SLICE_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long m = (long)blockIdx.x * 128 + wave * 32 + j;  // < ld always (ld is a multiple of 128)
+    const bool valid = m < M;
+    const float *frow = feat + (size_t)(valid ? m : M - 1) * DDNERF_FEAT_LD;
+    f32x16 Breg[12];
+    f32x16 out[8];
+    const float *wp = packed;
+    {
+        constexpr int N4 = 8 * (96 + 4), ROUNDS = (N4 + 255) / 256;
+        f32x4 pf[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            int i4 = r * 256 + tid;
+            if (i4 > N4 - 1) i4 = N4 - 1;
+            pf[r] = *(const f32x4 *)(wp + 4 * (size_t)i4);
+        }
+        load_features<8, 0, 3>(frow, h, Breg);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int i4 = r * 256 + tid;
+            if ((r + 1) * 256 <= N4 || i4 < N4) *(f32x4 *)(lds + 4 * i4) = pf[r];
+        }
+    }
+    __syncthreads();
+    const float *bias = packed;
+    layer_fwd_train<0, 96, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[0], lds, Breg, out, acts, ld, 0, m, tid, lane);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+    for (int l = 1; l <= 3; ++l) {
+        layer_fwd_train<1, 256, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[l], lds, Breg, out, acts, ld, 256 * l, m, tid, lane);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+    }
+    layer_fwd_train<1, 256, 8, 352, 0, true, 8>(wp, bias + fo.bias_off[4], lds, Breg, out, acts, ld, 256 * 4, m, tid, lane);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+    load_features<8, 0, 3>(frow, h, Breg);
+    __builtin_amdgcn_sched_barrier(0);
+    layer_fwd_train<2, 352, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[5], lds, Breg, out, acts, ld, 256 * 5, m, tid, lane);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+    for (int l = 6; l <= 7; ++l) {
+        layer_fwd_train<1, 256, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[l], lds, Breg, out, acts, ld, 256 * l, m, tid, lane);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+    }
+    layer_fwd_train<1, 256, 8, 288, 0, false, 8>(wp, bias + fo.bias_off[8], lds, Breg, out, acts, ld, ROW_FEAT, m, tid, lane);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+    load_features<11, 3, 1>(frow, h, Breg);
+    __builtin_amdgcn_sched_barrier(0);
+    layer_fwd_train<3, 288, 5, 128, 0, true, 4>(wp, bias + fo.bias_off[9], lds, Breg, out, acts, ld, ROW_DIR, m, tid, lane);
+    const float alpha = out[4][0];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Breg[b] = out[b];
+    layer_fwd_train<4, 128, 1, 0, 1, false, 0>(wp, bias + fo.bias_off[10], lds, Breg, out, acts, ld, 0, m, tid, lane);
+    if (valid) {
+        if (DEPTH) {
+            float *o = raw + (size_t)m * 6;
+            if (h == 0) {
+                *(float2 *)(o) = make_float2(out[0][0], out[0][1]);
+                *(float2 *)(o + 2) = make_float2(out[0][2], alpha);
+            } else {
+                *(float2 *)(o + 4) = make_float2(out[0][0], out[0][1]);
+            }
+        } else if (h == 0) {
+            *(f32x4 *)(raw + (size_t)m * 4) = f32x4{out[0][0], out[0][1], out[0][2], alpha};
+        }
+    }
+}
+
+static FwdOffsets fwd_offsets() {
+    FwdOffsets fo;
+    int off = 0;
+    for (int l = 0; l < NLAYERS; ++l) off += kLayerNB[l] * 32 * (kLayerK[l] + 4);
+    for (int l = 0; l < NLAYERS; ++l) {
+        fo.bias_off[l] = off;
+        off += kLayerNB[l] * 32;
+    }
+    return fo;
+}
+
+DDN_EXPORT int ddnerf_mlp_f32_forward_train(const float *feat, const float *packed, int depth_head, float *raw,
+                                            float *acts, long M, long ld, ddnerf_stream_t stream) {
+    DDN_REQUIRE(feat && packed && raw && acts, DDNERF_E_ARG);
+    DDN_REQUIRE(M > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ld >= M && ld % 128 == 0, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16), DDNERF_E_ALIGN);
+    FwdOffsets fo = fwd_offsets();
+    dim3 grid((unsigned)((M + 127) / 128));
+    if (depth_head)
+        hipLaunchKernelGGL(mlp_f32_fwd_train_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
+                           acts, M, ld);
+    else
+        hipLaunchKernelGGL(mlp_f32_fwd_train_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
+                           acts, M, ld);
+    return ddn_launch_status();
+}
+
+// ---- fused backward-data ------------------------------------------------------------------------------------
+// One backward step: NB tiles of the outgoing delta.  MASK_ROW0 >= 0: multiply by relu'(acts rows) (the tile of the
+// recorded activation is fetched before the MFMAs of its slice so that its latency hides under them).
+template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK>
+__device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *lds, const f32x16 (&Breg)[12],
+                                         f32x16 (&out)[8], const float *__restrict__ acts, float *__restrict__ deltas,
+                                         size_t ld, int row0, size_t col, int tid, int lane) {
+    constexpr int N4 = 8 * (K + 4);
+    constexpr int NEXT_N4 = NEXT_K > 0 ? 8 * (NEXT_K + 4) : 0;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float *cur = lds + ((PAR + b) & 1) * MAX_SLICE_FLOATS;
+        float *nxt = lds + ((PAR + b + 1) & 1) * MAX_SLICE_FLOATS;
+        wp += 4 * N4;
+        f32x16 act;
+        auto init = [&](f32x16 &a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+            if (MASK) act = load_tile_t(acts, ld, row0 + 32 * b, col, h);
+        };
+        auto post = [&](f32x16 &a) {
+            if (MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = act[r] > 0.0f ? a[r] : 0.0f;
+            }
+            store_tile_t(deltas, ld, row0 + 32 * b, col, h, a);
+        };
+        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+    }
+}
+
+template <bool DEPTH>
+__global__ __launch_bounds__(256, 1) void mlp_f32_bwd_data_kernel(const float *__restrict__ g_raw,
+                                                                  const float *__restrict__ packed_t,
+                                                                  const float *__restrict__ acts,
+                                                                  float *__restrict__ deltas, long M, long ld) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * MAX_SLICE_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long m = (long)blockIdx.x * 128 + wave * 32 + j;
+    const bool valid = m < M;
+    f32x16 Breg[12];
+    f32x16 out[8];
+    const float *wp = packed_t;
+    {
+        constexpr int N4 = 8 * (32 + 4), ROUNDS = (N4 + 255) / 256;
+        f32x4 pf[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            int i4 = r * 256 + tid;
+            if (i4 > N4 - 1) i4 = N4 - 1;
+            pf[r] = *(const f32x4 *)(wp + 4 * (size_t)i4);
+        }
+        // the d(raw) tile: tile row c = raw column c (rows 0..3 on lane half 0, rows 4,5 on lane half 1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Breg[8][r] = 0.0f;
+        if (valid) {
+            const float *g = g_raw + (size_t)m * (DEPTH ? 6 : 4);
+            if (h == 0) {
+                Breg[8][0] = g[0];
+                Breg[8][1] = g[1];
+                Breg[8][2] = g[2];
+                Breg[8][3] = g[3];
+            } else if (DEPTH) {
+                Breg[8][0] = g[4];
+                Breg[8][1] = g[5];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int i4 = r * 256 + tid;
+            if ((r + 1) * 256 <= N4 || i4 < N4) *(f32x4 *)(lds + 4 * i4) = pf[r];
+        }
+    }
+    __syncthreads();
+    // d0: d(dir hidden) = heads^T d(raw), masked by relu'(dir hidden)            4 slices: buffers 0,1,0,1 -> next in 0
+    step_bwd<10, 32, 4, 160, 0, true>(wp, lds, Breg, out, acts, deltas, ld, ROW_DIR, m, tid, lane);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Breg[b] = out[b];
+    // d1: d(feat) = W_dir[:, :256]^T d(dir hidden) + W_alpha^T d(raw)[3]; fc_feat has no activation
+    step_bwd<11, 160, 8, 256, 0, false>(wp, lds, Breg, out, acts, deltas, ld, ROW_FEAT, m, tid, lane);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+    // d2..d9: d(h_l) = W_{l+1}^T d(h_{l+1}) * relu'(h_l),  l = 7..0
+    for (int l = 7; l >= 1; --l) {
+        step_bwd<1, 256, 8, 256, 0, true>(wp, lds, Breg, out, acts, deltas, ld, 256 * l, m, tid, lane);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+    }
+    step_bwd<1, 256, 8, 0, 0, true>(wp, lds, Breg, out, acts, deltas, ld, 0, m, tid, lane);
+}
+
+DDN_EXPORT int ddnerf_mlp_f32_backward_data(const float *g_raw, const float *packed_t, const float *acts,
+                                            int depth_head, float *deltas, long M, long ld, ddnerf_stream_t stream) {
+    DDN_REQUIRE(g_raw && packed_t && acts && deltas, DDNERF_E_ARG);
+    DDN_REQUIRE(M > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ld >= M && ld % 128 == 0, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(packed_t, 16), DDNERF_E_ALIGN);
+    dim3 grid((unsigned)((M + 127) / 128));
+    if (depth_head)
+        hipLaunchKernelGGL(mlp_f32_bwd_data_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, acts,
+                           deltas, M, ld);
+    else
+        hipLaunchKernelGGL(mlp_f32_bwd_data_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, acts,
+                           deltas, M, ld);
+    return ddn_launch_status();
+}

@@ -4,70 +4,196 @@ hand-written backward kernel; PyTorch owns the graph, the optimiser and the RNG 
 Which gradients exist is dictated by the reference's graph: nothing flows through the
 samplers or the encoder inputs; the MLP needs weight gradients only (no gradient w.r.t. its 123 input
 features); compositing needs d(raw) from d(rgb_map) and d(weights); the DD head from d(mus), d(sigmas) and
-the two regularisers."""
+the two regularisers; the dp loss w.r.t. (w0, mus0, sig0).  Outputs nothing in the reference's losses reads
+(disp, acc, depth, corrected disparity, the Phi tails) are marked non-differentiable."""
 from __future__ import annotations
 
 import torch
 
 from . import ops
 
-
 # ---- MLP -------------------------------------------------------------------------------------------------
 _pack_cache = {}
 
 
-def _packed_weights(net):
+def _cached_pack(net, kind, builder):
     flat = net.flat_params()
-    key = (id(net), net.mlp_dtype)
-    tag = (flat.data_ptr(), flat._version, net.mlp_dtype)
+    key = (id(net), kind)
+    tag = (flat.data_ptr(), flat._version)
     hit = _pack_cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    if net.mlp_dtype == "fp32":
-        packed = ops.mlp_f32_pack(flat, net.depth_head)
-    else:
-        packed = ops.mlp_bf16_pack(flat, net.depth_head)
+    packed = builder(flat, net.depth_head)
     _pack_cache[key] = (tag, packed)
     return packed
 
 
-class _MLPFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, feat, net, *params):
-        packed = _packed_weights(net)
-        if net.mlp_dtype == "fp32":
-            raw = ops.mlp_f32_forward(feat, packed, net.depth_head)
-        else:
-            raw = ops.mlp_bf16_forward(feat, packed, net.depth_head)
-        ctx.net = net
-        ctx.save_for_backward(feat)
-        return raw
-
-    @staticmethod
-    def backward(ctx, g_raw):
-        raise NotImplementedError("MLP backward kernel (K2b) not built yet")
+def _packed_weights(net):
+    if net.mlp_dtype == "fp32":
+        return _cached_pack(net, "fp32", ops.mlp_f32_pack)
+    return _cached_pack(net, "bf16", ops.mlp_bf16_pack)
 
 
-def mlp(feat, net):
-    """feat [M,128] (fp32, or bf16 for the bf16 kernel) -> raw [M,4|6]"""
-    if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
-        return _MLPFunction.apply(feat, net, *net.parameters())
+def _forward_kernel(feat, net):
     packed = _packed_weights(net)
     if net.mlp_dtype == "fp32":
         return ops.mlp_f32_forward(feat, packed, net.depth_head)
     return ops.mlp_bf16_forward(feat, packed, net.depth_head)
 
 
+def mlp_weight_grads(net, feat, acts, deltas, g_raw):
+    """dW_l = delta_l^T (input_l)^T over the sample axis -- plain GEMMs on the two transposed [feature][sample]
+    matrices the fused kernels stored (handed to the BLAS library); bias gradients are row sums.
+    Returns the flat gradient buffer (registration order) and its per-parameter views."""
+    M = feat.shape[0]
+    params = list(net.parameters())
+    flat_g = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=feat.device)
+    views, off = [], 0
+    for p in params:
+        views.append(flat_g[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+    gv = {name: v for (name, _), v in zip(net.named_parameters(), views)}
+    A = lambda r0, rows: acts[r0:r0 + rows, :M]      # [rows, M] (row = feature)
+    D = lambda r0, rows: deltas[r0:r0 + rows, :M]
+    x_xyz, x_dir = feat[:, :96], feat[:, 96:123]      # [M, 96], [M, 27] (row = sample)
+    for l in range(8):
+        d = D(256 * l, 256)
+        w = gv["layers_xyz.%d.weight" % l]
+        if l == 0:
+            torch.mm(d, x_xyz, out=w)
+        elif l == 5:
+            w[:, :96] = torch.mm(d, x_xyz)
+            w[:, 96:] = torch.mm(d, A(256 * 4, 256).t())
+        else:
+            torch.mm(d, A(256 * (l - 1), 256).t(), out=w)
+        torch.sum(d, dim=1, out=gv["layers_xyz.%d.bias" % l])
+    d_feat, d_dir = D(ops.ROW_FEAT, 256), D(ops.ROW_DIR, 128)
+    a_feat, a_dir = A(ops.ROW_FEAT, 256), A(ops.ROW_DIR, 128)
+    torch.mm(d_feat, A(256 * 7, 256).t(), out=gv["fc_feat.weight"])
+    torch.sum(d_feat, dim=1, out=gv["fc_feat.bias"])
+    g_alpha = g_raw[:, 3]
+    torch.mv(a_feat, g_alpha, out=gv["fc_alpha.weight"].view(-1))
+    gv["fc_alpha.bias"].copy_(g_alpha.sum().reshape(1))
+    wd = gv["layers_dir.0.weight"]
+    wd[:, :256] = torch.mm(d_dir, a_feat.t())
+    wd[:, 256:] = torch.mm(d_dir, x_dir)
+    torch.sum(d_dir, dim=1, out=gv["layers_dir.0.bias"])
+    g_rgb = g_raw[:, :3]
+    torch.mm(g_rgb.t(), a_dir.t(), out=gv["fc_rgb.weight"])
+    torch.sum(g_rgb, dim=0, out=gv["fc_rgb.bias"])
+    if net.depth_head:
+        g_ms = g_raw[:, 4:6]
+        torch.mm(g_ms.t(), a_dir.t(), out=gv["fc_mu_sigma.weight"])
+        torch.sum(g_ms, dim=0, out=gv["fc_mu_sigma.bias"])
+    return flat_g, views
+
+
+class _MLPFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, net, *params):
+        if net.mlp_dtype != "fp32":
+            raise NotImplementedError("training runs on the fp32 MLP kernels; the bf16 kernel is inference-only so far")
+        packed = _packed_weights(net)
+        raw, acts = ops.mlp_f32_forward_train(feat, packed, net.depth_head)
+        ctx.net = net
+        ctx.save_for_backward(feat, acts)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        net = ctx.net
+        feat, acts = ctx.saved_tensors
+        g_raw = g_raw.contiguous()
+        packed_t = _cached_pack(net, "fp32_t", ops.mlp_f32_pack_t)
+        deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head)
+        flat_g, views = mlp_weight_grads(net, feat, acts, deltas, g_raw)
+        net.last_flat_grad = flat_g  # the data-parallel bucket (ddnerf_amd.dist) reduces this buffer
+        return (None, None) + tuple(views)
+
+
+def mlp(feat, net):
+    """feat [M,128] (fp32, or k-ordered bf16 for the bf16 kernel) -> raw [M,4|6]"""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+        return _MLPFunction.apply(feat, net, *net.parameters())
+    return _forward_kernel(feat, net)
+
+
 # ---- DD head ---------------------------------------------------------------------------------------------
+class _DDHeadFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw6, smooth, dist_reg):
+        d = ops.dd_head(raw6, smooth, dist_reg)
+        ctx.save_for_backward(raw6)
+        ctx.dist_reg = float(dist_reg)
+        outs = (d["mus"], d["sigmas"], d["left"], d["part"], d["ssig"], d["sleft"], d["spart"], d["scal"])
+        ctx.mark_non_differentiable(*outs[2:7])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_mus, g_sigmas, _gl, _gp, _gss, _gsl, _gsp, g_scal):
+        (raw6,) = ctx.saved_tensors
+        g_raw6 = torch.zeros_like(raw6)
+        ops.dd_head_backward_(raw6, ctx.dist_reg, g_mus, g_sigmas, g_scal, g_raw6)
+        return g_raw6, None, None
+
+
 def dd_head(raw6, smooth, dist_reg):
+    if torch.is_grad_enabled() and raw6.requires_grad:
+        o = _DDHeadFunction.apply(raw6, float(smooth), float(dist_reg))
+        return dict(zip(("mus", "sigmas", "left", "part", "ssig", "sleft", "spart", "scal"), o))
     return ops.dd_head(raw6, smooth, dist_reg)
 
 
 # ---- compositing -----------------------------------------------------------------------------------------
+class _CompositeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, t_vals, rays, noise, mus, white_bkgd, blender):
+        c = ops.composite_forward(raw, t_vals, rays, noise, mus, white_bkgd, blender)
+        ctx.save_for_backward(raw, t_vals, rays, noise)
+        ctx.flags = (bool(white_bkgd), bool(blender))
+        ctx.has_cdisp = c["cdisp"] is not None
+        nd = [c["disp"], c["acc"], c["depth"]] + ([c["cdisp"]] if ctx.has_cdisp else [])
+        ctx.mark_non_differentiable(*nd)
+        if ctx.has_cdisp:
+            return c["rgb_map"], c["weights"], c["disp"], c["acc"], c["depth"], c["cdisp"]
+        return c["rgb_map"], c["weights"], c["disp"], c["acc"], c["depth"]
+
+    @staticmethod
+    def backward(ctx, g_rgb_map, g_weights, *_unused):
+        raw, t_vals, rays, noise = ctx.saved_tensors
+        if g_rgb_map is None:
+            g_rgb_map = torch.zeros((raw.shape[0], 3), dtype=torch.float32, device=raw.device)
+        g_raw = ops.composite_backward(raw, t_vals, rays, noise, ctx.flags[0], ctx.flags[1], g_rgb_map, g_weights)
+        return g_raw, None, None, None, None, None, None
+
+
 def composite(raw, t_vals, rays, noise, mus, white_bkgd, blender):
+    """-> dict(rgb_map, disp, acc, weights, depth, cdisp)"""
+    if torch.is_grad_enabled() and raw.requires_grad:
+        o = _CompositeFunction.apply(raw, t_vals, rays, noise, None if mus is None else mus.detach(), white_bkgd, blender)
+        d = dict(rgb_map=o[0], weights=o[1], disp=o[2], acc=o[3], depth=o[4], cdisp=o[5] if len(o) > 5 else None)
+        return d
     return ops.composite_forward(raw, t_vals, rays, noise, mus, white_bkgd, blender)
 
 
 # ---- dp loss ---------------------------------------------------------------------------------------------
+class _DPLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w0, mus0, sig0, t1, t0, w1, left0, part0, blender):
+        loss = ops.dp_loss_forward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender)
+        ctx.save_for_backward(w0, mus0, sig0, t1, t0, w1, left0, part0)
+        ctx.blender = bool(blender)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        w0, mus0, sig0, t1, t0, w1, left0, part0 = ctx.saved_tensors
+        gw, gm, gs = ops.dp_loss_backward(t1, t0, w1, w0, mus0, sig0, left0, part0, ctx.blender, g)
+        return gw, gm, gs, None, None, None, None, None, None
+
+
 def dp_loss(t1, t0, w1, w0, mus0, sig0, left0, part0, blender):
+    """models/dd_utils.py:6-78; differentiable w.r.t. (w0, mus0, sig0) like the reference's call site"""
+    if torch.is_grad_enabled() and (w0.requires_grad or mus0.requires_grad or sig0.requires_grad):
+        return _DPLossFunction.apply(w0, mus0, sig0, t1, t0, w1, left0, part0, blender)
     return ops.dp_loss_forward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender)

@@ -189,3 +189,81 @@ def dp_loss_forward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender):
                                                  _ptr(part0), n, nc, nf, int(blender), _ptr(loss), _ptr(ws), _stream()),
                "ddnerf_dp_loss_forward")
     return loss
+
+
+# ---- backward entry points ---------------------------------------------------------------------------------
+def composite_backward(raw, t_vals, rays, noise, white_bkgd, blender, g_rgb_map, g_weights):
+    raw, t_vals, rays, noise = _f32c(raw, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays"), _f32c(noise, "noise")
+    g_rgb_map, g_weights = _f32c(g_rgb_map, "g_rgb_map"), _f32c(g_weights, "g_weights")
+    n, S, ldr = raw.shape
+    g_raw = torch.empty_like(raw)
+    flags = (1 if white_bkgd else 0) | (2 if blender else 0)
+    _lib.check(_lib.lib().ddnerf_composite_backward(_ptr(raw), ldr, _ptr(t_vals), _ptr(rays), _ptr(noise), n, S, flags,
+                                                    _ptr(g_rgb_map), _ptr(g_weights), _ptr(g_raw), _stream()),
+               "ddnerf_composite_backward")
+    return g_raw
+
+
+def dd_head_backward_(raw6, dist_reg, g_mus, g_sigmas, g_scal, g_raw6):
+    """adds the DD-head gradient into g_raw6[..., 4:6] in place"""
+    raw6 = _f32c(raw6, "raw6")
+    n, nc = raw6.shape[0], raw6.shape[1]
+    _lib.check(_lib.lib().ddnerf_dd_head_backward(_ptr(raw6), n, nc, float(dist_reg), _ptr(_f32c(g_mus, "g_mus")),
+                                                  _ptr(_f32c(g_sigmas, "g_sigmas")), _ptr(_f32c(g_scal, "g_scal")),
+                                                  _ptr(g_raw6), _stream()), "ddnerf_dd_head_backward")
+    return g_raw6
+
+
+def dp_loss_backward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender, g_loss):
+    t1, t0, w1, w0, mus0, sig0, left0, part0 = (_f32c(t, "dp_loss arg") for t in (t1, t0, w1, w0, mus0, sig0, left0, part0))
+    n, nc = w0.shape
+    nf = w1.shape[1]
+    g_loss = _f32c(g_loss.reshape(1), "g_loss")
+    gw, gm, gs = torch.empty_like(w0), torch.empty_like(w0), torch.empty_like(w0)
+    ws = torch.empty(_lib.lib().ddnerf_dp_loss_workspace_bytes(n), dtype=torch.uint8, device=w0.device)
+    _lib.check(_lib.lib().ddnerf_dp_loss_backward(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0),
+                                                  _ptr(part0), n, nc, nf, int(blender), _ptr(g_loss), _ptr(gw), _ptr(gm),
+                                                  _ptr(gs), _ptr(ws), _stream()), "ddnerf_dp_loss_backward")
+    return gw, gm, gs
+
+
+ACT_ROWS = 2432
+ROW_FEAT, ROW_DIR = 2048, 2304
+
+
+def mlp_f32_pack_t(params_flat, depth_head):
+    params_flat = _f32c(params_flat, "params")
+    packed = torch.empty(_lib.lib().ddnerf_mlp_f32_packed_t_floats(int(depth_head)), dtype=torch.float32,
+                         device=params_flat.device)
+    _lib.check(_lib.lib().ddnerf_mlp_f32_pack_t(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()),
+               "ddnerf_mlp_f32_pack_t")
+    return packed
+
+
+def mlp_f32_forward_train(feat, packed, depth_head):
+    """forward + recorded activations: returns raw [M,4|6], acts [2432, ld] (transposed: row = feature)"""
+    feat = _f32c(feat, "feat")
+    M = feat.shape[0]
+    ld = (M + 127) // 128 * 128
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+    acts = torch.empty((ACT_ROWS, ld), dtype=torch.float32, device=feat.device)
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_mlp_f32_forward_train(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts),
+                                                           M, ld, _stream()), "ddnerf_mlp_f32_forward_train")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw, acts
+
+
+def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head):
+    g_raw = _f32c(g_raw, "g_raw")
+    M = g_raw.shape[0]
+    ld = acts.shape[1]
+    deltas = torch.empty_like(acts)
+    _lib.check(_lib.lib().ddnerf_mlp_f32_backward_data(_ptr(g_raw), _ptr(packed_t), _ptr(acts), int(depth_head),
+                                                       _ptr(deltas), M, ld, _stream()), "ddnerf_mlp_f32_backward_data")
+    return deltas

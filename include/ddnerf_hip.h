@@ -130,6 +130,44 @@ int ddnerf_dp_loss_forward(const float *t1, const float *t0, const float *w1, co
                            const float *sig0, const float *left0, const float *part0, int n, int nc, int nf,
                            int blender, float *loss, void *workspace, ddnerf_stream_t stream);
 
+/* ---- training: backward entry points --------------------------------------------------------------------
+ * Gradient structure of the reference's graph: nothing flows through the samplers or the encoder;
+ * the MLPs need parameter gradients only; compositing needs d(raw) from d(rgb_map) and (coarse level) d(weights);
+ * the DD head from d(mus), d(sigmas) and its regularisers; the dp loss w.r.t. (w0, mus0, sig0). */
+
+/* backward of volume_render_radiance_field w.r.t. raw.  g_weights may be NULL.  g_raw [n,S,ldr]: columns 0..3 are
+ * written, columns >= 4 are zeroed (ddnerf_dd_head_backward then ADDS into columns 4,5). */
+int ddnerf_composite_backward(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
+                              int n, int S, int flags, const float *g_rgb_map, const float *g_weights, float *g_raw,
+                              ddnerf_stream_t stream);
+
+/* backward of the DD head: g_mus / g_sigmas [n,nc] (may be NULL), g_scal[4] = upstream gradients of
+ * {mus_loss, sig_loss, mus_reg, sig_reg} (may be NULL); adds into g_raw6[..., 4:6]. */
+int ddnerf_dd_head_backward(const float *raw6, int n, int nc, float dist_reg, const float *g_mus, const float *g_sigmas,
+                            const float *g_scal, float *g_raw6, ddnerf_stream_t stream);
+
+/* backward of estimate_dp_loss w.r.t. (w0, mus0, sig0); g_loss[0] = upstream gradient of the scalar loss.
+ * workspace as for the forward. */
+int ddnerf_dp_loss_backward(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,
+                            const float *sig0, const float *left0, const float *part0, int n, int nc, int nf,
+                            int blender, const float *g_loss, float *g_w0, float *g_mus, float *g_sig, void *workspace,
+                            ddnerf_stream_t stream);
+
+/* fp32 MLP training kernels.  acts / deltas: [ddnerf_mlp_act_rows()][ld] fp32, ld = M rounded up to 128, stored
+ * TRANSPOSED (row = feature, column = sample): rows 256*l.. layers_xyz.l (l=0..7), 2048.. fc_feat, 2304.. layers_dir.0.
+ *   forward_train : forward + records every layer's output in `acts`
+ *   pack_t        : transposed weight images for the backward-data kernel (once per weight update)
+ *   backward_data : g_raw [M,4|6] -> every layer's pre-activation gradient in `deltas` (one fused kernel)
+ * Weight gradients are then the plain GEMMs  dW_l = deltas[rows of l] x acts[rows of l-1]^T  over the sample axis
+ * (bias gradients: row sums), left to the BLAS library on the host side. */
+size_t ddnerf_mlp_act_rows(void);
+size_t ddnerf_mlp_f32_packed_t_floats(int depth_head);
+int ddnerf_mlp_f32_pack_t(const float *params, int depth_head, float *packed_t, ddnerf_stream_t stream);
+int ddnerf_mlp_f32_forward_train(const float *feat, const float *packed, int depth_head, float *raw, float *acts, long M,
+                                 long ld, ddnerf_stream_t stream);
+int ddnerf_mlp_f32_backward_data(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
+                                 float *deltas, long M, long ld, ddnerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
