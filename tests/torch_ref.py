@@ -46,3 +46,31 @@ def mlp(x, sd, depth_head):
     if depth_head:
         outs.append(lin(hd, "fc_mu_sigma"))
     return torch.cat(outs, -1)
+
+
+def dp_loss(t1, t0, w1, w0, mus0, sig0, left0, part0, blender):
+    """models/dd_utils.py:6-78 in plain torch (any dtype), incl. the un-filtered left_tails gather."""
+    import math
+    if blender:
+        rows = w1.sum(1) > 1e-10
+        if rows.sum() == 0:
+            return w0.sum() * 0
+        w0, w1, mus0, sig0, part0, t1, t0 = w0[rows], w1[rows], mus0[rows], sig0[rows], part0[rows], t1[rows], t0[rows]
+    eps = 1e-12
+    p0 = (w0 + eps) / (w0 + eps).sum(-1, keepdim=True)
+    p1 = (w1 + eps) / (w1 + eps).sum(-1, keepdim=True)
+    mr = t0[:, :-1] + mus0 * (t0[:, 1:] - t0[:, :-1])
+    sr = sig0 * (t0[:, 1:] - t0[:, :-1])
+    cdf = torch.minimum(torch.ones((), dtype=p0.dtype, device=p0.device), torch.cumsum(p0[:, :-1], -1))
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf, torch.ones_like(cdf[:, :1])], -1)
+    mask = t1[:, None, :] > t0[:, :, None]
+    est, idx = torch.max(torch.where(mask, cdf[:, :, None], cdf[:, :1, None]), -2)
+    g = lambda x: torch.gather(x, index=idx, dim=-1)
+    x = (t1 - g(mr)) / g(sr)
+    phi = 0.5 * (1 + torch.erf(x / math.sqrt(2.0)))
+    est = est + ((phi - g(left0[: w0.shape[0]])) / g(part0)) * g(p0)
+    est = torch.where(est > 1, torch.ones_like(est), est)
+    d = est[:, 1:] - est[:, :-1]
+    d = torch.where(d < 0, torch.zeros_like(d), d)
+    q = (d + eps) / (d + eps).sum(-1, keepdim=True)
+    return torch.nn.functional.kl_div(q.log(), p1, reduction="mean")
