@@ -95,6 +95,7 @@ class _MLPFunction(torch.autograd.Function):
             raise NotImplementedError("training runs on the fp32 MLP kernels; the bf16 kernel is inference-only so far")
         packed = _packed_weights(net)
         raw, acts = ops.mlp_f32_forward_train(feat, packed, net.depth_head)
+        net._fwd_calls = getattr(net, "_fwd_calls", 0) + 1
         ctx.net = net
         ctx.save_for_backward(feat, acts)
         return raw
@@ -108,6 +109,9 @@ class _MLPFunction(torch.autograd.Function):
         deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head)
         flat_g, views = mlp_weight_grads(net, feat, acts, deltas, g_raw)
         net.last_flat_grad = flat_g  # the data-parallel bucket (ddnerf_amd.dist) reduces this buffer
+        reducer = getattr(net, "grad_reducer", None)
+        if reducer is not None:
+            reducer.on_flat_grad_ready(net, flat_g)
         return (None, None) + tuple(views)
 
 

@@ -1,0 +1,50 @@
+"""One training iteration of the reference's loop (train_model.py:132-177) on the HIP path, optionally data
+parallel.  Loss assembly, the two Adam optimisers and the schedules are the reference's; what changes is that
+nothing forces a host sync per iteration (the reference calls .item() twice per step for logging)."""
+from __future__ import annotations
+
+import torch
+
+from . import dist as ddp
+from . import schedules
+
+
+class TrainStepper:
+    def __init__(self, model, cfg, dist=False, optimizers=None):
+        self.model, self.cfg = model, cfg
+        self.dd = cfg.nerf.type == "DDNerfModel"
+        if optimizers is None:  # train_model.py:84-98: one optimiser per network, lr set per step
+            opt = getattr(torch.optim, cfg.optimizer.type)
+            optimizers = [opt(model.coarse.parameters(), lr=cfg.optimizer.lr)]
+            if cfg.nerf.type != "GeneralMipNerfModel":
+                optimizers.append(opt(model.fine.parameters(), lr=cfg.optimizer.lr))
+        self.optims = optimizers
+        self.smooth = schedules.SmoothingSchedule(cfg)
+        self.buckets = ddp.GradBuckets([model.fine, model.coarse]) if dist else None
+        if dist:
+            ddp.broadcast_parameters([model.coarse, model.fine])
+        self.iter = 0
+
+    def step(self, ray_origins, ray_directions, ray_rad, target):
+        cfg, model, i = self.cfg, self.model, self.iter
+        self.smooth.apply(model.cfg, i)
+        model.train()
+        lr = schedules.lr_at(i, cfg.experiment.train_iters)
+        for o in self.optims:
+            for gp in o.param_groups:
+                gp["lr"] = lr
+        out = model.run_iter(ray_origins, ray_directions, ray_rad, mode="train", rgb_target=target)
+        losses = [torch.nn.functional.mse_loss(out[j]["rgb"], target) for j in range(len(out))]
+        loss = sum(cfg.train_params.loss_coeficients[j] * losses[j] for j in range(len(out)))  # :159-161
+        if self.dd:
+            dp = out[1]["dp_loss"].mean()                                                      # :163-167
+            loss = loss + cfg.train_params.dp_coeficient * dp
+            losses.append(dp)
+        loss.backward()
+        if self.buckets is not None:
+            self.buckets.finish()
+        for o in self.optims:
+            o.step()
+            o.zero_grad()
+        self.iter += 1
+        return loss.detach(), [l.detach() for l in losses], out
