@@ -19,6 +19,7 @@ SOURCES = {
     "composite.hip": EXACT,
     "samplers.hip": EXACT,
     "dp_loss.hip": EXACT,
+    "raygen.hip": EXACT,
     "mlp_f32.hip": [],
     "mlp_f32_train.hip": [],
     "mlp_bf16.hip": [],

@@ -267,3 +267,27 @@ def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head):
     _lib.check(_lib.lib().ddnerf_mlp_f32_backward_data(_ptr(g_raw), _ptr(packed_t), _ptr(acts), int(depth_head),
                                                        _ptr(deltas), M, ld, _stream()), "ddnerf_mlp_f32_backward_data")
     return deltas
+
+
+# ---- ray generation -------------------------------------------------------------------
+def ray_bundle(H, W, focal, cam2world, device="cuda"):
+    """general_utils/nerf_helpers.py:67-125 -> origins [H,W,3], directions [H,W,3], radii [H,W,1]"""
+    import ctypes
+
+    pose = torch.as_tensor(cam2world, dtype=torch.float32).cpu().contiguous()[:3, :4].contiguous()
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=device)
+    o, d, r = e(H, W, 3), e(H, W, 3), e(H, W, 1)
+    with torch.cuda.device(o.device):
+        _lib.check(_lib.lib().ddnerf_ray_bundle(int(H), int(W), float(focal), ctypes.c_void_p(pose.data_ptr()), _ptr(o),
+                                                _ptr(d), _ptr(r), _stream()), "ddnerf_ray_bundle")
+    return o, d, r
+
+
+def ndc_rays(H, W, focal, origins, directions, near=1.0):
+    """data_utils/dataset_helpers.py:3-42 -> NDC origins, directions [H,W,3], radii [H,W,1]"""
+    origins, directions = _f32c(origins, "origins"), _f32c(directions, "directions")
+    o, d = torch.empty_like(origins), torch.empty_like(directions)
+    r = torch.empty((H, W, 1), dtype=torch.float32, device=origins.device)
+    _lib.check(_lib.lib().ddnerf_ndc_rays(int(H), int(W), float(focal), float(near), _ptr(origins), _ptr(directions), _ptr(o),
+                                          _ptr(d), _ptr(r), _stream()), "ddnerf_ndc_rays")
+    return o, d, r

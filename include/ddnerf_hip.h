@@ -130,6 +130,15 @@ int ddnerf_dp_loss_forward(const float *t1, const float *t0, const float *w1, co
                            const float *sig0, const float *left0, const float *part0, int n, int nc, int nf,
                            int blender, float *loss, void *workspace, ddnerf_stream_t stream);
 
+/* ---- ray generation (the caller immediately upstream of the path) ------------------------------------------
+ * get_ray_bundle  general_utils/nerf_helpers.py:67-125: cam2world [host] = 3x4 (or 4x4) row-major pose;
+ * outputs origins/directions [H,W,3], radii [H,W] (= [H,W,1]) incl. the 1e-5 zero nudges. */
+int ddnerf_ray_bundle(int H, int W, float focal, const float *cam2world_host, float *origins, float *directions,
+                      float *radii, ddnerf_stream_t stream);
+/* ndc_mipnerf_rays  data_utils/dataset_helpers.py:3-42: NDC warp of a bundle + radii from neighbouring origins */
+int ddnerf_ndc_rays(int H, int W, float focal, float near_, const float *origins, const float *directions,
+                    float *origins_ndc, float *directions_ndc, float *radii, ddnerf_stream_t stream);
+
 /* ---- training: backward entry points --------------------------------------------------------------------
  * Gradient structure of the reference's graph: nothing flows through the samplers or the encoder;
  * the MLPs need parameter gradients only; compositing needs d(raw) from d(rgb_map) and (coarse level) d(weights);

@@ -443,7 +443,27 @@ def gen_aten_orders():
     save("aten_orders", **out)
 
 
+def gen_raygen():
+    """get_ray_bundle / ndc_mipnerf_rays (the callers immediately upstream of the path)"""
+    from data_utils.dataset_helpers import ndc_mipnerf_rays
+
+    rng = np.random.Generator(np.random.PCG64(91))
+    out = {}
+    for tag, H, W, focal in (("a", 9, 7, 11.5), ("b", 6, 12, 20.0)):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        pose = np.concatenate([q, rng.standard_normal((3, 1)) * 3], 1).astype(np.float32)
+        if tag == "b":
+            pose[1, 3] = 0.0  # exercises the zero nudge of the origins
+            pose[:3, :3] = np.eye(3, dtype=np.float32)  # ... and of the directions (centre pixel)
+        o, d, r = ref_helpers.get_ray_bundle(H, W, focal, T(pose))
+        o, d = o.clone(), d.clone()
+        on, dn, rn = ndc_mipnerf_rays(H, W, focal, o, d, 1)
+        out.update({tag + "_pose": pose, tag + "_hwf": np.array([H, W, focal]), tag + "_o": o, tag + "_d": d, tag + "_r": r,
+                    tag + "_on": on, tag + "_dn": dn, tag + "_rn": rn})
+    save("raygen", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders"]
+    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen"]
     for w in which:
         globals()["gen_" + w]()

@@ -223,3 +223,18 @@ def test_full_size_properties(ops):
     assert torch.equal(t1, t1b)
     raw_b = ops.mlp_f32_forward(feat, packed, True).reshape(n, nc, 6)
     assert torch.equal(raw, raw_b)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_ray_generation(ops, golden, tag):
+    """get_ray_bundle / ndc_mipnerf_rays on device vs the reference (next-tier row: the caller upstream of the path)"""
+    g = golden("raygen")
+    H, W, focal = g[tag + "_hwf"]
+    H, W = int(H), int(W)
+    o, d, r = ops.ray_bundle(H, W, float(focal), g[tag + "_pose"])
+    assert np.array_equal(host(o), g[tag + "_o"])
+    assert maxerr(host(d), g[tag + "_d"]) <= 2.4e-7
+    assert maxerr(host(r), g[tag + "_r"]) <= 1e-7 * float(np.abs(g[tag + "_r"]).max()) + 1e-9
+    on, dn, rn = ops.ndc_rays(H, W, float(focal), dev(g[tag + "_o"]), dev(g[tag + "_d"]), 1.0)
+    assert relerr(host(on), g[tag + "_on"]) <= 2e-6 and relerr(host(dn), g[tag + "_dn"]) <= 2e-6
+    assert relerr(host(rn), g[tag + "_rn"]) <= 2e-5
