@@ -70,6 +70,7 @@ class _RayDatasetBase:
         o, d, r = ops.ray_bundle(self.H, self.W, self.focal, pose, device=self.device)
         if self.ndc:
             o, d, r = ops.ndc_rays(self.H, self.W, self.focal, o, d, self.near)
+            r = r.unsqueeze(-1)
         return o, d, r
 
 
@@ -79,7 +80,7 @@ class TrainDataset(_RayDatasetBase):
     def __init__(self, poses, images, focal, ndc_rays=False, single_image_mode=False, device="cuda"):
         super().__init__(poses, images, focal, ndc_rays, device)
         self.single_image_mode = single_image_mode
-        o, d, r = zip(*(tuple(x.reshape(-1, x.shape[-1]) for x in self.bundle(p)) for p in self.poses))
+        o, d, r = zip(*((b[0].reshape(-1, 3), b[1].reshape(-1, 3), b[2].reshape(-1, 1)) for b in map(self.bundle, self.poses)))
         tgt = [im.reshape(-1, 3).to(device) for im in self.images]
         if single_image_mode:
             self.origins, self.directions, self.radii, self.target = list(o), list(d), list(r), tgt

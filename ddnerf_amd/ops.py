@@ -284,10 +284,10 @@ def ray_bundle(H, W, focal, cam2world, device="cuda"):
 
 
 def ndc_rays(H, W, focal, origins, directions, near=1.0):
-    """data_utils/dataset_helpers.py:3-42 -> NDC origins, directions [H,W,3], radii [H,W,1]"""
+    """data_utils/dataset_helpers.py:3-42 -> NDC origins, directions [H,W,3], radii [H,W] (the reference's shape)"""
     origins, directions = _f32c(origins, "origins"), _f32c(directions, "directions")
     o, d = torch.empty_like(origins), torch.empty_like(directions)
-    r = torch.empty((H, W, 1), dtype=torch.float32, device=origins.device)
+    r = torch.empty((H, W), dtype=torch.float32, device=origins.device)
     _lib.check(_lib.lib().ddnerf_ndc_rays(int(H), int(W), float(focal), float(near), _ptr(origins), _ptr(directions), _ptr(o),
                                           _ptr(d), _ptr(r), _stream()), "ddnerf_ndc_rays")
     return o, d, r
