@@ -123,13 +123,22 @@ __device__ __forceinline__ void layer(const float *__restrict__ &wp, const float
                                       const f32x16 (&Breg)[12], f32x16 (&out)[8], int tid, int lane) {
     constexpr int N4 = 8 * (K + 4);  // float4 pieces per slice of this layer
     constexpr int NEXT_N4 = NEXT_K > 0 ? 8 * (NEXT_K + 4) : 0;
+    const int h = lane >> 5;
+    f32x16 bcur = bias_tile(bias, h);  // one exposed fetch per layer; every later tile's bias is fetched a slice ahead
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const float *cur = lds + ((PAR + b) & 1) * MAX_SLICE_FLOATS;
         float *nxt = lds + ((PAR + b + 1) & 1) * MAX_SLICE_FLOATS;
         wp += 4 * N4;  // now points at the slice after the current one
-        if (b + 1 < NB) slice_step<KIND, K, N4>(wp, bias + 32 * b, cur, nxt, Breg, out[b], tid, lane);
-        else slice_step<KIND, K, NEXT_N4>(wp, bias + 32 * b, cur, nxt, Breg, out[b], tid, lane);
+        f32x16 bnext;
+        auto init = [&](f32x16 &a) {
+            a = bcur;
+            if (b + 1 < NB) bnext = bias_tile(bias + 32 * (b + 1), h);
+        };
+        auto post = [](f32x16 &) {};
+        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+        if (b + 1 < NB) bcur = bnext;
     }
 }
 

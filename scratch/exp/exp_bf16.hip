@@ -19,7 +19,7 @@
 // while stage s feeds the MFMAs; two stage buffers, one barrier per stage.
 #include <utility>
 
-#include "common.h"
+#include "/root/repo/ddnerf_amd/csrc/common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -231,7 +231,7 @@ __device__ __forceinline__ const bf16x8 &bsrc(const bf16x8 (&H)[16], const bf16x
 template <int KIND, int K, int NBLK, int B0, int NCONV, int DMA_BYTES>
 __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, const bf16x8 (&H)[16], const bf16x8 (&X)[8],
                                               bf16x8 (&Hn)[16], f32x16 (&keep)[2], bool relu, int lane, int wave,
-                                              const char *__restrict__ dma_src, char *dma_dst) {
+                                              const char *__restrict__ dma_src, unsigned dma_dst) {
     constexpr int NKS = K / 16, P = NBLK * NKS, DEPTH = 4, ROWB = 2 * K + 16, SLB = slice_bytes(K);
     // the NEXT stage's DMA pieces of this wave (piece index = wave + 8 i) are spread over this stage's MFMA stream
     constexpr int PIECES = DMA_BYTES / 1024, NP = (PIECES + 7) / 8;
@@ -240,7 +240,6 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
     const char *b_lane = cur + 32 * ROWB + 16 * (lane >> 5);
     bf16x8 ring[DEPTH];
     f32x16 acc[2];
-    f32x4 pf = {0.f, 0.f, 0.f, 0.f};  // the weight piece in flight (global -> VGPR -> LDS)
     auto read_a = [&](auto pc) {
         constexpr int p = decltype(pc)::value;
         ring[p % DEPTH] = *(const bf16x8 *)(a_lane + (p / NKS) * SLB + 32 * (p % NKS));
@@ -260,26 +259,20 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
     static_for<P>([&](auto pc) {
         constexpr int p = decltype(pc)::value, b = p / NKS, ks = p % NKS;
         acc[b & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % DEPTH], bsrc<KIND, ks>(H, X), acc[b & 1], 0, 0, 0);
+#ifndef EXP_NOLDS
         if constexpr (p + DEPTH < P) read_a(std::integral_constant<int, p + DEPTH>{});
+#endif
+#ifndef EXP_NOBIAS
         if constexpr (b + 1 < NBLK && ks >= NKS - 5 && ks < NKS - 1)  // next block's bias, one piece per step
             read_bias(std::integral_constant<int, b + 1>{}, std::integral_constant<int, ks - (NKS - 5)>{});
-        // Next stage's weights: each wave moves its 1-KiB pieces global -> 4 VGPRs -> LDS, one piece in flight, spread
-        // over the MFMA stream.  (LDS-DMA needs no VGPRs but one global_load_lds costs its wave 60-180 issue cycles:
-        // measured 18 % of the kernel; a global_load_dwordx4 + ds_write_b128 pair is far cheaper to issue.)  The two
-        // waves of a SIMD (w, w+4) alternate roles at the two slots of a period so their stalls do not coincide.
-        if constexpr (NP > 0 && p / DMA_EVERY < NP && DMA_EVERY >= 4 && (p % DMA_EVERY == DMA_EVERY / 4 || p % DMA_EVERY == (3 * DMA_EVERY) / 4)) {
+#endif
+        if constexpr (NP > 0 && p % DMA_EVERY == DMA_EVERY / 2 && p / DMA_EVERY < NP) {
             constexpr int i = p / DMA_EVERY;
-            constexpr bool slot_b = p % DMA_EVERY == (3 * DMA_EVERY) / 4;
-            auto ok = [&](int ii) { return (ii + 1) * 8 <= PIECES || wave + 8 * ii < PIECES; };
-            auto ld = [&](int ii) { pf = *(const f32x4 *)(dma_src + (wave + 8 * ii) * 1024 + lane * 16); };
-            auto st = [&](int ii) { *(f32x4 *)(dma_dst + (wave + 8 * ii) * 1024 + lane * 16) = pf; };
-            if (wave < 4) {
-                if (!slot_b) { if (ok(i)) ld(i); }
-                else { if (ok(i)) st(i); }
-            } else {
-                if (!slot_b) { if (i > 0 && ok(i - 1)) st(i - 1); }
-                else { if (ok(i)) ld(i); }
-            }
+            const int piece = wave + 8 * i;
+#ifndef EXP_NODMA
+            if ((i + 1) * 8 <= PIECES || piece < PIECES)
+                dma_piece(dma_src + piece * 1024 + lane * 16, dma_dst + piece * 1024);
+#endif
         }
         if constexpr (b > 0 && ks >= 1 && ks <= 4) {  // re-pack the previous tile behind this block's first MFMAs
             constexpr int pb = b - 1, q = ks - 1;     // quarter q: accumulator registers 4q..4q+3 -> one packed pair x2
@@ -292,11 +285,11 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
         }
         __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (NP > 0) {
-        static_assert(DMA_EVERY >= 4 && NP <= P / DMA_EVERY, "every piece needs its two slots in the MFMA stream");
-        if (wave >= 4 && ((NP * 8 <= PIECES) || wave + 8 * (NP - 1) < PIECES))  // second-half waves: last piece still in VGPRs
-            *(f32x4 *)(dma_dst + (wave + 8 * (NP - 1)) * 1024 + lane * 16) = pf;
-    }
+    static_for<(NP > P / DMA_EVERY ? NP - P / DMA_EVERY : 0)>([&](auto ic) {  // pieces the stream had no slot for
+        constexpr int i = P / DMA_EVERY + decltype(ic)::value;
+        const int piece = wave + 8 * i;
+        if ((i + 1) * 8 <= PIECES || piece < PIECES) dma_piece(dma_src + piece * 1024 + lane * 16, dma_dst + piece * 1024);
+    });
     constexpr int lb = NBLK - 1;  // the stage's last tile is re-packed right away
     if constexpr (B0 + lb < NCONV) {
         Hn[2 * (B0 + lb)] = to_bfrag<0>(acc[lb & 1], relu);
@@ -319,11 +312,13 @@ __device__ __forceinline__ void layer(const char *__restrict__ &wp, char *lds, c
         constexpr int nblk = kNB[L] - first < kSPS[L] ? kNB[L] - first : kSPS[L];
         char *cur = lds + ((PAR + st) & 1) * STAGE_BYTES_MAX;
         char *nxt = lds + ((PAR + st + 1) & 1) * STAGE_BYTES_MAX;
-        dma_wait();       // (only the prologue's LDS-DMA of the very first stage is ever pending here)
-        __syncthreads();  // every wave has parked its pieces of stage `st`; the other buffer is free again
+#ifndef EXP_NOSYNC
+        dma_wait();       // this wave's pieces of stage `st` (issued during the previous stage) have landed ...
+        __syncthreads();  // ... and so have everybody else's; the other buffer is free again
+#endif
         wp += stage_bytes(L, st);
         constexpr int nbytes = st + 1 < NST ? stage_bytes(L, st + 1) : (NEXT >= 0 ? stage_bytes(NEXT >= 0 ? NEXT : 0, 0) : 0);
-        stage_compute<KIND, K, nblk, first, NCONV, nbytes>(cur, H, X, Hn, keep, relu, lane, wave, wp, nxt);
+        stage_compute<KIND, K, nblk, first, NCONV, nbytes>(cur, H, X, Hn, keep, relu, lane, wave, wp, lds_addr_of(nxt));
     });
 }
 
