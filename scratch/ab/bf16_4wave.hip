@@ -23,7 +23,7 @@
 // loop into lgkmcnt(0)); two stage buffers, one barrier per stage.
 #include <utility>
 
-#include "common.h"
+#include "/root/repo/ddnerf_amd/csrc/common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -151,9 +151,6 @@ DDN_EXPORT int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *p
 }
 
 // ---- fused forward ----------------------------------------------------------------------------------------
-#ifndef BF16_DEPTH
-#define BF16_DEPTH 4  // A fragments are read this many k-steps ahead of their MFMAs
-#endif
 #define WG_THREADS 256
 #define WG_WAVES 4
 #define NCOL 2                       // 32-sample column blocks per wave
@@ -236,7 +233,7 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
                                               const bf16x8 (&X)[NCOL][8], bf16x8 (&Hn)[NCOL][16],
                                               f32x16 (&keep)[NCOL][2], bool relu, int lane, int wave,
                                               const char *__restrict__ dma_src, char *dma_dst) {
-    constexpr int NKS = K / 16, P = NBLK * NKS, DEPTH = BF16_DEPTH, ROWB = 2 * K + 16, SLB = slice_bytes(K);
+    constexpr int NKS = K / 16, P = NBLK * NKS, DEPTH = 4, ROWB = 2 * K + 16, SLB = slice_bytes(K);
     constexpr int PIECES = DMA_BYTES / 1024, NP = (PIECES + WG_WAVES - 1) / WG_WAVES;  // pieces of this wave
     constexpr int DMA_EVERY = NP > 0 ? P / NP : 1;
     static_assert(NP == 0 || DMA_EVERY >= 2, "every piece needs a load slot and a store slot");

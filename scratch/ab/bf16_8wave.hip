@@ -9,21 +9,17 @@
 //               (element j of lane half h = feature 16s + 8(j>>2) + 4h + (j&3)); W is packed in the same k
 //               order (per 16 columns the four quads are stored [0,2,1,3]), and so are the bf16 feature rows the
 //               encode kernel writes (include/ddnerf_hip.h, DDNERF "k-order").
-// Activations never leave registers.  A wave owns 64 samples = two 32-sample column blocks, so every A fragment
-// read from LDS feeds TWO MFMAs: measured on the first version (8 waves x 32 samples) the LDS array, not the matrix
-// pipe, was the limiter (A reads + weight-stage writes ~80 % of LDS cycles).  4 waves (one per SIMD, 512-register
-// file) = 256 samples per workgroup share every LDS-staged weight byte; a finished tile is re-packed to bf16 into
-// the NEXT layer's B file right away (ping-pong), so only four accumulator tiles are live.
+// Activations never leave registers.  A wave owns 32 samples: B file 64 VGPR (256 features as packed bf16) +
+// 128 accumulator registers; 8 waves (2 per SIMD) = 256 samples per workgroup share every LDS-staged weight
+// byte, and one wave's layer epilogue (bias, ReLU, bf16 pack: VALU) overlaps its SIMD partner's MFMAs.
 //
 // Weights: repacked once per update into the exact LDS image -- 32-row slices, row stride K+8 bf16 (the 16-byte
 // pad makes the b128 fragment reads bank-conflict free), grouped in STAGES of <= 66 KiB that are 1-KiB multiples --
-// stored in consumption order.  While stage s feeds the MFMAs, stage s+1 is moved global -> 4 VGPRs -> LDS one 1-KiB
-// piece per wave at a time, spread over the MFMA stream (LDS-DMA would need no VGPRs, but one global_load_lds costs
-// its wave 60-180 issue cycles, and -- issued through the builtin -- makes hipcc turn every counted lgkmcnt(N) of the
-// loop into lgkmcnt(0)); two stage buffers, one barrier per stage.
+// stored in consumption order.  Stage s+1 is streamed global->LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
+// while stage s feeds the MFMAs; two stage buffers, one barrier per stage.
 #include <utility>
 
-#include "common.h"
+#include "/root/repo/ddnerf_amd/csrc/common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -151,13 +147,8 @@ DDN_EXPORT int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *p
 }
 
 // ---- fused forward ----------------------------------------------------------------------------------------
-#ifndef BF16_DEPTH
-#define BF16_DEPTH 4  // A fragments are read this many k-steps ahead of their MFMAs
-#endif
-#define WG_THREADS 256
-#define WG_WAVES 4
-#define NCOL 2                       // 32-sample column blocks per wave
-#define WG_SAMPLES (WG_WAVES * NCOL * 32)
+#define WG_THREADS 512
+#define WG_SAMPLES 256
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
@@ -168,8 +159,11 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// LDS-DMA of the very first stage only (nothing to overlap it with); asm so that hipcc's wait-count pass does not see a
-// pending LDS write (it would degrade every later counted lgkmcnt(N) to lgkmcnt(0)).
+// LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 1 KiB (64 lanes x 16 B) from global memory to
+// LDS[m0 + lane*16] without touching VGPRs.  Issued through inline asm on purpose: with the builtin, hipcc's wait-count
+// pass sees a pending LDS write and degrades EVERY later `s_waitcnt lgkmcnt(N)` of the MFMA loop to lgkmcnt(0)
+// (measured: 633 x lgkmcnt(0) vs counted waits without it), i.e. each MFMA group stalls for a full LDS round trip.
+// The asm form is invisible to that pass; completion is waited for explicitly (dma_wait) before the stage barrier.
 __device__ __forceinline__ void dma_piece(const char *__restrict__ gsrc_lane, unsigned lds_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -181,12 +175,13 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ unsigned lds_addr_of(const char *p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
 }
+// whole stage at once (prologue only)
 __device__ __forceinline__ void dma_stage(const char *__restrict__ src, char *dst, int bytes, int wave, int lane) {
     const unsigned base = lds_addr_of(dst);
-    for (int off = wave * 1024; off < bytes; off += WG_WAVES * 1024) dma_piece(src + off + lane * 16, base + off);
+    for (int off = wave * 1024; off < bytes; off += 8 * 1024) dma_piece(src + off + lane * 16, base + off);
 }
 
-// two floats -> one packed bf16 pair (one v_cvt_pk_bf16_f32); ReLU on the bf16 bit patterns (v_pk_max_i16)
+// two floats -> one packed bf16 pair (one v_cvt_pk_bf16_f32)
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -194,22 +189,21 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16(float a, float b, bool relu) {
     f32x2 v = {a, b};
     bf16x2 r = __builtin_convertvector(v, bf16x2);
-    if (relu) {
+    if (relu) {  // ReLU on the bf16 bit patterns: signed 16-bit max with 0 (v_pk_max_i16)
         const s16x2 z = {0, 0};
         r = __builtin_bit_cast(bf16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, r), z));
     }
     return __builtin_bit_cast(unsigned, r);
 }
-
-// The two B files (this layer's and the next layer's activations, 2 x 128 registers) are homed in the accumulator
-// half of the unified register file: MFMA reads its B operand from there directly, and the arch VGPRs stay free
-// for the accumulator tiles, the A ring and the VALU temporaries.  Left to itself hipcc keeps shuttling them
-// (5,600 v_accvgpr moves and 109 spills measured); defining every packed word through this one-instruction asm
-// gives it the AGPR register class from birth.
-__device__ __forceinline__ unsigned to_agpr(unsigned v) {
-    unsigned a;
-    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
-    return a;
+// half of an accumulator tile (registers 8s..8s+7) -> the B fragment of k-step s of the next layer
+template <int S>
+__device__ __forceinline__ bf16x8 to_bfrag(const f32x16 &acc, bool relu) {
+    u32x4 w;
+    w[0] = pack_bf16(acc[8 * S + 0], acc[8 * S + 1], relu);
+    w[1] = pack_bf16(acc[8 * S + 2], acc[8 * S + 3], relu);
+    w[2] = pack_bf16(acc[8 * S + 4], acc[8 * S + 5], relu);
+    w[3] = pack_bf16(acc[8 * S + 6], acc[8 * S + 7], relu);
+    return __builtin_bit_cast(bf16x8, w);
 }
 
 // B-operand source of k-step ks of a layer: KIND 0 first layer (xyz, X[0..5]); 1 hidden (H[ks]); 2 skip layer
@@ -226,25 +220,27 @@ __device__ __forceinline__ const bf16x8 &bsrc(const bf16x8 (&H)[16], const bf16x
     } else return H[KS];
 }
 
-// One stage: NBLK 32-row slices out of LDS buffer `cur`.  The order of the statements below IS the instruction
-// schedule (sched_barrier(0) after every step keeps hipcc from re-serialising it): one A fragment -> NCOL MFMAs;
-// A fragments are read DEPTH k-steps ahead into a ring; the bias tile of block b+1 (its accumulators' start value,
-// shared by the column blocks) is read during block b; the bf16 re-pack of the previous block's tiles is placed
-// behind this block's first MFMAs; the next stage's weight pieces travel global -> VGPR -> LDS in the gaps.
+#define SG_MFMA 0x008
+#define SG_VALU 0x002
+#define SG_DSRD 0x100
+
+// One stage: NBLK 32-row slices out of LDS buffer `cur`.  Explicitly software-pipelined, in program order
+// (pinned with sched_group_barrier): A fragments are read DEPTH MFMAs ahead into a ring of DEPTH registers sets;
+// the bias tile of block b+1 (= its accumulator start value) is read during block b; the bf16 re-pack of a
+// finished tile (VALU) is placed behind the first MFMAs of the next block.
 template <int KIND, int K, int NBLK, int B0, int NCONV, int DMA_BYTES>
-__device__ __forceinline__ void stage_compute(const char *__restrict__ cur, const bf16x8 (&H)[NCOL][16],
-                                              const bf16x8 (&X)[NCOL][8], bf16x8 (&Hn)[NCOL][16],
-                                              f32x16 (&keep)[NCOL][2], bool relu, int lane, int wave,
+__device__ __forceinline__ void stage_compute(const char *__restrict__ cur, const bf16x8 (&H)[16], const bf16x8 (&X)[8],
+                                              bf16x8 (&Hn)[16], f32x16 (&keep)[2], bool relu, int lane, int wave,
                                               const char *__restrict__ dma_src, char *dma_dst) {
-    constexpr int NKS = K / 16, P = NBLK * NKS, DEPTH = BF16_DEPTH, ROWB = 2 * K + 16, SLB = slice_bytes(K);
-    constexpr int PIECES = DMA_BYTES / 1024, NP = (PIECES + WG_WAVES - 1) / WG_WAVES;  // pieces of this wave
-    constexpr int DMA_EVERY = NP > 0 ? P / NP : 1;
-    static_assert(NP == 0 || DMA_EVERY >= 2, "every piece needs a load slot and a store slot");
+    constexpr int NKS = K / 16, P = NBLK * NKS, DEPTH = 4, ROWB = 2 * K + 16, SLB = slice_bytes(K);
+    // the NEXT stage's DMA pieces of this wave (piece index = wave + 8 i) are spread over this stage's MFMA stream
+    constexpr int PIECES = DMA_BYTES / 1024, NP = (PIECES + 7) / 8;
+    constexpr int DMA_EVERY = NP > 0 ? (P / NP > 0 ? P / NP : 1) : 1;
     const char *a_lane = cur + (lane & 31) * ROWB + 16 * (lane >> 5);
     const char *b_lane = cur + 32 * ROWB + 16 * (lane >> 5);
     bf16x8 ring[DEPTH];
-    f32x16 acc[2][NCOL];
-    f32x4 pf[2];  // weight pieces in flight (global -> VGPR -> LDS), two deep
+    f32x16 acc[2];
+    f32x4 pf = {0.f, 0.f, 0.f, 0.f};  // the weight piece in flight (global -> VGPR -> LDS)
     auto read_a = [&](auto pc) {
         constexpr int p = decltype(pc)::value;
         ring[p % DEPTH] = *(const bf16x8 *)(a_lane + (p / NKS) * SLB + 32 * (p % NKS));
@@ -252,73 +248,70 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
     auto read_bias = [&](auto bc, auto gc) {  // rows 8g + 4h + (0..3) of block b -> accumulator registers 4g..4g+3
         constexpr int b = decltype(bc)::value, g = decltype(gc)::value;
         const f32x4 v = *(const f32x4 *)(b_lane + b * SLB + 32 * g);
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c) {
-            acc[b & 1][c][4 * g + 0] = v.x;
-            acc[b & 1][c][4 * g + 1] = v.y;
-            acc[b & 1][c][4 * g + 2] = v.z;
-            acc[b & 1][c][4 * g + 3] = v.w;
-        }
-    };
-    auto piece_ok = [&](int i) { return (i + 1) * WG_WAVES <= PIECES || wave + WG_WAVES * i < PIECES; };
-    auto ld_piece = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if (piece_ok(i)) pf[i & 1] = *(const f32x4 *)(dma_src + (wave + WG_WAVES * i) * 1024 + lane * 16);
-    };
-    auto st_piece = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if (piece_ok(i)) *(f32x4 *)(dma_dst + (wave + WG_WAVES * i) * 1024 + lane * 16) = pf[i & 1];
-    };
-    auto repack = [&](auto pbc, auto cc, auto qc) {  // quarter q of tile (block pb, column c) -> 2 packed pairs of Hn
-        constexpr int pb = decltype(pbc)::value, c = decltype(cc)::value, q = decltype(qc)::value;
-        if constexpr (B0 + pb < NCONV) {
-            u32x4 w = __builtin_bit_cast(u32x4, Hn[c][2 * (B0 + pb) + q / 2]);
-            w[2 * (q & 1) + 0] = to_agpr(pack_bf16(acc[pb & 1][c][4 * q + 0], acc[pb & 1][c][4 * q + 1], relu));
-            w[2 * (q & 1) + 1] = to_agpr(pack_bf16(acc[pb & 1][c][4 * q + 2], acc[pb & 1][c][4 * q + 3], relu));
-            Hn[c][2 * (B0 + pb) + q / 2] = __builtin_bit_cast(bf16x8, w);
-        }
+        acc[b & 1][4 * g + 0] = v.x;
+        acc[b & 1][4 * g + 1] = v.y;
+        acc[b & 1][4 * g + 2] = v.z;
+        acc[b & 1][4 * g + 3] = v.w;
     };
     static_for<4>([&](auto g) { read_bias(std::integral_constant<int, 0>{}, g); });
     static_for<(DEPTH < P ? DEPTH : P)>([&](auto p) { read_a(p); });
     __builtin_amdgcn_sched_barrier(0);
+    // the order below IS the schedule: sched_barrier(0) after every step keeps hipcc from re-serialising it
     static_for<P>([&](auto pc) {
         constexpr int p = decltype(pc)::value, b = p / NKS, ks = p % NKS;
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c)
-            acc[b & 1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % DEPTH], bsrc<KIND, ks>(H[c], X[c]),
-                                                                    acc[b & 1][c], 0, 0, 0);
+        acc[b & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % DEPTH], bsrc<KIND, ks>(H, X), acc[b & 1], 0, 0, 0);
         if constexpr (p + DEPTH < P) read_a(std::integral_constant<int, p + DEPTH>{});
         if constexpr (b + 1 < NBLK && ks >= NKS - 5 && ks < NKS - 1)  // next block's bias, one piece per step
             read_bias(std::integral_constant<int, b + 1>{}, std::integral_constant<int, ks - (NKS - 5)>{});
-        if constexpr (NP > 0 && p / DMA_EVERY < NP && p % DMA_EVERY == 0) {
-            // slot of piece i: first park piece i-2 (its load has had two periods, > 500 cycles, to land), then fetch i
+        // Next stage's weights: each wave moves its 1-KiB pieces global -> 4 VGPRs -> LDS, one piece in flight, spread
+        // over the MFMA stream.  (LDS-DMA needs no VGPRs but one global_load_lds costs its wave 60-180 issue cycles:
+        // measured 18 % of the kernel; a global_load_dwordx4 + ds_write_b128 pair is far cheaper to issue.)  The two
+        // waves of a SIMD (w, w+4) alternate roles at the two slots of a period so their stalls do not coincide.
+        if constexpr (NP > 0 && p / DMA_EVERY < NP && DMA_EVERY >= 4 && (p % DMA_EVERY == DMA_EVERY / 4 || p % DMA_EVERY == (3 * DMA_EVERY) / 4)) {
             constexpr int i = p / DMA_EVERY;
-            if constexpr (i >= 2) st_piece(std::integral_constant<int, i - 2>{});
-            ld_piece(std::integral_constant<int, i>{});
+            constexpr bool slot_b = p % DMA_EVERY == (3 * DMA_EVERY) / 4;
+            auto ok = [&](int ii) { return (ii + 1) * 8 <= PIECES || wave + 8 * ii < PIECES; };
+            auto ld = [&](int ii) { pf = *(const f32x4 *)(dma_src + (wave + 8 * ii) * 1024 + lane * 16); };
+            auto st = [&](int ii) { *(f32x4 *)(dma_dst + (wave + 8 * ii) * 1024 + lane * 16) = pf; };
+            if (wave < 4) {
+                if (!slot_b) { if (ok(i)) ld(i); }
+                else { if (ok(i)) st(i); }
+            } else {
+                if (!slot_b) { if (i > 0 && ok(i - 1)) st(i - 1); }
+                else { if (ok(i)) ld(i); }
+            }
         }
-        if constexpr (b > 0 && ks >= 1 && ks <= 4) {  // re-pack the previous block's tiles, a quarter per step
-            static_for<NCOL>([&](auto cc) {
-                repack(std::integral_constant<int, b - 1>{}, cc, std::integral_constant<int, ks - 1>{});
-            });
+        if constexpr (b > 0 && ks >= 1 && ks <= 4) {  // re-pack the previous tile behind this block's first MFMAs
+            constexpr int pb = b - 1, q = ks - 1;     // quarter q: accumulator registers 4q..4q+3 -> one packed pair x2
+            if constexpr (B0 + pb < NCONV) {
+                u32x4 w = __builtin_bit_cast(u32x4, Hn[2 * (B0 + pb) + q / 2]);
+                w[2 * (q & 1) + 0] = pack_bf16(acc[pb & 1][4 * q + 0], acc[pb & 1][4 * q + 1], relu);
+                w[2 * (q & 1) + 1] = pack_bf16(acc[pb & 1][4 * q + 2], acc[pb & 1][4 * q + 3], relu);
+                Hn[2 * (B0 + pb) + q / 2] = __builtin_bit_cast(bf16x8, w);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (NP >= 2) st_piece(std::integral_constant<int, (NP >= 2 ? NP - 2 : 0)>{});  // the last two pieces
-    if constexpr (NP >= 1) st_piece(std::integral_constant<int, (NP >= 1 ? NP - 1 : 0)>{});
-    constexpr int lb = NBLK - 1;  // the stage's last block is re-packed right away
-    static_for<NCOL>([&](auto cc) {
-        static_for<4>([&](auto qc) { repack(std::integral_constant<int, lb>{}, cc, qc); });
-        constexpr int c = decltype(cc)::value;
-        keep[c][0] = acc[lb & 1][c];  // the layer's last tile (heads: rgb / mu,sigma rows; dir layer: alpha row)
-    });
+    if constexpr (NP > 0) {
+        static_assert(DMA_EVERY >= 4 && NP <= P / DMA_EVERY, "every piece needs its two slots in the MFMA stream");
+        if (wave >= 4 && ((NP * 8 <= PIECES) || wave + 8 * (NP - 1) < PIECES))  // second-half waves: last piece still in VGPRs
+            *(f32x4 *)(dma_dst + (wave + 8 * (NP - 1)) * 1024 + lane * 16) = pf;
+    }
+    constexpr int lb = NBLK - 1;  // the stage's last tile is re-packed right away
+    if constexpr (B0 + lb < NCONV) {
+        Hn[2 * (B0 + lb)] = to_bfrag<0>(acc[lb & 1], relu);
+        Hn[2 * (B0 + lb) + 1] = to_bfrag<1>(acc[lb & 1], relu);
+    }
+    keep[0] = acc[lb & 1];                         // the layer's last tile (heads: rgb / mu,sigma rows)
+    if constexpr (NBLK > 1) keep[1] = acc[(lb - 1) & 1];
 }
 
-// One layer = its stages.  On entry the layer's first stage sits in LDS buffer PAR (parked by the previous stage).
-// NEXT = layer whose first stage is fetched during this layer's last stage (-1: none).
+// One layer = its stages.  On entry the layer's first stage is in flight (or landed) in LDS buffer PAR.
+// NEXT = layer whose first stage is prefetched during this layer's last stage (-1: none).
 template <int L, int KIND, int NEXT, int PAR, int NCONV>
-__device__ __forceinline__ void layer(const char *__restrict__ &wp, char *lds, const bf16x8 (&H)[NCOL][16],
-                                      const bf16x8 (&X)[NCOL][8], bf16x8 (&Hn)[NCOL][16], f32x16 (&keep)[NCOL][2],
-                                      bool relu, int wave, int lane) {
+__device__ __forceinline__ void layer(const char *__restrict__ &wp, char *lds, const bf16x8 (&H)[16],
+                                      const bf16x8 (&X)[8], bf16x8 (&Hn)[16], f32x16 (&keep)[2], bool relu, int wave,
+                                      int lane) {
     constexpr int K = kK[L], NST = stages_of(L);
     static_for<NST>([&](auto stc) {
         constexpr int st = decltype(stc)::value;
@@ -335,32 +328,23 @@ __device__ __forceinline__ void layer(const char *__restrict__ &wp, char *lds, c
 }
 
 template <bool DEPTH_HEAD>
-__global__ __launch_bounds__(WG_THREADS, 1) void mlp_bf16_fwd_kernel(const unsigned short *__restrict__ feat,
+__global__ __launch_bounds__(WG_THREADS, 2) void mlp_bf16_fwd_kernel(const unsigned short *__restrict__ feat,
                                                                      const char *__restrict__ packed,
                                                                      float *__restrict__ raw, long M) {
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    long m[NCOL];
-    const unsigned short *frow[NCOL];
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-        m[c] = (long)blockIdx.x * WG_SAMPLES + wave * (NCOL * 32) + c * 32 + j;
-        frow[c] = feat + (size_t)(m[c] < M ? m[c] : M - 1) * DDNERF_FEAT_LD;
-    }
-    bf16x8 HA[NCOL][16], HB[NCOL][16], X[NCOL][8];
-    f32x16 keep[NCOL][2];
+    const long m = (long)blockIdx.x * WG_SAMPLES + wave * 32 + j;
+    const bool valid = m < M;
+    const unsigned short *frow = feat + (size_t)(valid ? m : M - 1) * DDNERF_FEAT_LD;
+
+    bf16x8 HA[16], HB[16], X[8];
+    f32x16 keep[2];
     const char *wp = packed;
     dma_stage(wp, lds, stage_bytes(0, 0), wave, lane);
     // features (bf16, k-order): lane half h takes the second 16 bytes of every 16-column group
-    auto load_x = [&](auto g0c, auto g1c) {  // feature groups [g0, g1) of both column blocks (re-fetched, not held)
-        constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
 #pragma unroll
-        for (int c = 0; c < NCOL; ++c)
-#pragma unroll
-            for (int g = g0; g < g1; ++g) X[c][g] = *(const bf16x8 *)(frow[c] + 16 * g + 8 * h);
-    };
-    load_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});  // xyz: dead again after layer 0
+    for (int g = 0; g < 8; ++g) X[g] = *(const bf16x8 *)(frow + 16 * g + 8 * h);
 
     // parity of the LDS buffer holding a layer's first stage: L0 has 1 stage (buffer 0), every later layer has an
     // even number of stages and starts in buffer 1
@@ -369,33 +353,26 @@ __global__ __launch_bounds__(WG_THREADS, 1) void mlp_bf16_fwd_kernel(const unsig
     layer<2, 1, 3, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
     layer<3, 1, 4, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);
     layer<4, 1, 5, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
-    load_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
     layer<5, 2, 6, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);    // cat(xyz, h) 352 -> 256, 4 stages
     layer<6, 1, 7, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
     layer<7, 1, 8, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);
     layer<8, 1, 9, 1, 8>(wp, lds, HB, X, HA, keep, false, wave, lane);   // fc_feat: no activation
-    load_x(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});  // view-dir columns
     layer<9, 3, 10, 1, 4>(wp, lds, HA, X, HB, keep, true, wave, lane);   // dir layer (128, ReLU) + alpha row
-    float alpha[NCOL];
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) alpha[c] = keep[c][0][0];             // row 128 = block 4, register 0, lane half 0
+    const float alpha = keep[0][0];                                      // row 128 = block 4, register 0, lane half 0
     layer<10, 4, -1, 1, 0>(wp, lds, HB, X, HA, keep, false, wave, lane);  // heads
+    const f32x16 &o = keep[0];
 
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-        const f32x16 &o = keep[c][0];
-        if (m[c] < M) {
-            if (DEPTH_HEAD) {
-                float *op = raw + (size_t)m[c] * 6;
-                if (h == 0) {
-                    *(float2 *)(op) = make_float2(o[0], o[1]);
-                    *(float2 *)(op + 2) = make_float2(o[2], alpha[c]);
-                } else {
-                    *(float2 *)(op + 4) = make_float2(o[0], o[1]);  // rows 4, 5 = raw mu, raw sigma
-                }
-            } else if (h == 0) {
-                *(f32x4 *)(raw + (size_t)m[c] * 4) = f32x4{o[0], o[1], o[2], alpha[c]};
+    if (valid) {
+        if (DEPTH_HEAD) {
+            float *op = raw + (size_t)m * 6;
+            if (h == 0) {
+                *(float2 *)(op) = make_float2(o[0], o[1]);
+                *(float2 *)(op + 2) = make_float2(o[2], alpha);
+            } else {
+                *(float2 *)(op + 4) = make_float2(o[0], o[1]);  // rows 4, 5 = raw mu, raw sigma
             }
+        } else if (h == 0) {
+            *(f32x4 *)(raw + (size_t)m * 4) = f32x4{o[0], o[1], o[2], alpha};
         }
     }
 }

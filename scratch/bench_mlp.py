@@ -1,6 +1,6 @@
 """micro-benchmark of the fused MLP kernels alone (fine-pass size), HIP-event timed"""
 import sys, torch, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ddnerf_amd import ops, synthetic
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
