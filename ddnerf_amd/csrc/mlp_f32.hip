@@ -57,7 +57,7 @@ static PackPlan make_plan(int depth_head) {
     off = 0;
     for (int l = 0; l < NLAYERS; ++l) {
         p.slice_off[l] = off;
-        off += kLayerNB[l] * 32 * (kLayerK[l] + 4);
+        off += kLayerNB[l] * slice_floats(kLayerK[l]);
     }
     for (int l = 0; l < NLAYERS; ++l) {
         p.bias_off[l] = off;
@@ -101,9 +101,14 @@ __global__ void mlp_f32_pack_kernel(const float *__restrict__ P, PackPlan pl, fl
     }
     for (l = NLAYERS - 1; l > 0; --l)
         if (idx >= pl.slice_off[l]) break;
-    int ld = kLayerK[l] + 4, local = idx - pl.slice_off[l];
-    int o = local / ld, c = local % ld;  // slices of a layer are contiguous: o runs over all NB*32 rows
-    packed[idx] = c < kLayerK[l] ? src_weight(P, pl, l, o, c) : 0.0f;
+    const int ld = kLayerK[l] + 4, local = idx - pl.slice_off[l];
+    const int sl = local / slice_floats(kLayerK[l]), within = local % slice_floats(kLayerK[l]);
+    float v = 0.0f;
+    if (within < 32 * ld) {
+        const int o = 32 * sl + within / ld, c = within % ld;
+        if (c < kLayerK[l]) v = src_weight(P, pl, l, o, c);
+    }
+    packed[idx] = v;
 }
 
 DDN_EXPORT int ddnerf_mlp_f32_pack(const float *params, int depth_head, float *packed, ddnerf_stream_t stream) {
@@ -121,8 +126,8 @@ DDN_EXPORT int ddnerf_mlp_f32_pack(const float *params, int depth_head, float *p
 template <int KIND, int K, int NB, int NEXT_K, int PAR>
 __device__ __forceinline__ void layer(const float *__restrict__ &wp, const float *__restrict__ bias, float *lds,
                                       const f32x16 (&Breg)[12], f32x16 (&out)[8], int tid, int lane) {
-    constexpr int N4 = 8 * (K + 4);  // float4 pieces per slice of this layer
-    constexpr int NEXT_N4 = NEXT_K > 0 ? 8 * (NEXT_K + 4) : 0;
+    constexpr int N4 = slice_floats(K) / 4;  // float4 pieces per slice of this layer
+    constexpr int NEXT_N4 = NEXT_K > 0 ? slice_floats(NEXT_K) / 4 : 0;
     const int h = lane >> 5;
     f32x16 bcur = bias_tile(bias, h);  // one exposed fetch per layer; every later tile's bias is fetched a slice ahead
 #pragma unroll
@@ -175,20 +180,13 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_kernel(const float *__rest
     // stage slice 0 synchronously, fetch the sample's 128 features into B layout meanwhile
     const float *wp = packed;
     {
-        constexpr int N4 = 8 * (96 + 4), ROUNDS = (N4 + 255) / 256;
+        constexpr int ROUNDS = slice_floats(96) / 1024;
         f32x4 pf[ROUNDS];
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            int i4 = r * 256 + tid;
-            if (i4 > N4 - 1) i4 = N4 - 1;
-            pf[r] = *(const f32x4 *)(wp + 4 * (size_t)i4);
-        }
+        for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(wp + 4 * (size_t)(r * 256 + tid));
         load_features<8, 0, 3>(frow, h, Breg);  // xyz features; dead again after layer 0
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int i4 = r * 256 + tid;
-            if ((r + 1) * 256 <= N4 || i4 < N4) *(f32x4 *)(lds + 4 * i4) = pf[r];
-        }
+        for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(lds + 4 * (r * 256 + tid)) = pf[r];
     }
     __syncthreads();
 

@@ -6,7 +6,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define MAX_SLICE_FLOATS (32 * (352 + 4))
+// a packed slice = 32 rows of (K + 4) floats, padded to a whole number of 256-thread x float4 copy rounds (1024
+// floats): a partial last round would be a predicated load that hipcc sinks BELOW the MFMA block, next to its
+// store, exposing a full L2 round trip per slice (measured: MFMA pipe only 80 % busy before this padding).
+__host__ __device__ constexpr int slice_floats(int K) { return (32 * (K + 4) + 1023) / 1024 * 1024; }
+#define MAX_SLICE_FLOATS (slice_floats(352))
 
 // ---- fused forward ----------------------------------------------------------------------------------
 // B-operand register file of a wave: Breg[0..7] hidden activations, Breg[8..10] xyz features (96),
@@ -76,23 +80,17 @@ template <int KIND, int K, int PF_N4, class Init, class Post>
 __device__ __forceinline__ void slice_step_hooks(const float *__restrict__ next_src, const float *cur, float *nxt,
                                                  const f32x16 (&Breg)[12], f32x16 &acc, int tid, int lane, Init &&init,
                                                  Post &&post) {
-    constexpr int ROUNDS = (PF_N4 + 255) / 256;
+    static_assert(PF_N4 % 256 == 0, "slices are padded to whole copy rounds");
+    constexpr int ROUNDS = PF_N4 / 256;
     f32x4 pf[ROUNDS > 0 ? ROUNDS : 1];
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        int i4 = r * 256 + tid;
-        if (i4 > PF_N4 - 1) i4 = PF_N4 - 1;  // tail lanes re-read the last piece; their copy is not stored
-        pf[r] = *(const f32x4 *)(next_src + 4 * (size_t)i4);
-    }
+    for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(next_src + 4 * (size_t)(r * 256 + tid));
     init(acc);
     __builtin_amdgcn_sched_barrier(0);  // keep the fetches ABOVE the MFMA block: their latency hides under it
     slice_mfma<KIND, K>(cur, Breg, acc, lane);
     __builtin_amdgcn_sched_barrier(0);  // and the LDS commit BELOW it
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int i4 = r * 256 + tid;
-        if ((r + 1) * 256 <= PF_N4 || i4 < PF_N4) *(f32x4 *)(nxt + 4 * i4) = pf[r];
-    }
+    for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(nxt + 4 * (r * 256 + tid)) = pf[r];
     post(acc);
     __syncthreads();
 }

@@ -57,7 +57,7 @@ static PlanT make_plan_t(int depth_head) {
     off = 0;
     for (int d = 0; d < NBSTEPS; ++d) {
         p.step_off[d] = off;
-        off += kBNB[d] * 32 * (kBK[d] + 4);
+        off += kBNB[d] * slice_floats(kBK[d]);
     }
     p.total = off;
     return p;
@@ -90,8 +90,13 @@ __global__ void mlp_f32_pack_t_kernel(const float *__restrict__ P, PlanT pl, flo
     int d = NBSTEPS - 1;
     while (d > 0 && idx < pl.step_off[d]) --d;
     const int ld = kBK[d] + 4, local = idx - pl.step_off[d];
-    const int c = local / ld, o = local % ld;
-    packed[idx] = o < kBK[d] ? src_wt(P, pl, d, c, o) : 0.0f;
+    const int sl = local / slice_floats(kBK[d]), within = local % slice_floats(kBK[d]);
+    float v = 0.0f;
+    if (within < 32 * ld) {
+        const int c = 32 * sl + within / ld, o = within % ld;
+        if (o < kBK[d]) v = src_wt(P, pl, d, c, o);
+    }
+    packed[idx] = v;
 }
 
 DDN_EXPORT int ddnerf_mlp_f32_pack_t(const float *params, int depth_head, float *packed_t, ddnerf_stream_t stream) {
@@ -137,8 +142,8 @@ template <int KIND, int K, int NB, int NEXT_K, int PAR, bool RELU, int NSTORE>
 __device__ __forceinline__ void layer_fwd_train(const float *__restrict__ &wp, const float *__restrict__ bias, float *lds,
                                                 const f32x16 (&Breg)[12], f32x16 (&out)[8], float *__restrict__ acts,
                                                 size_t ld, int row0, size_t col, int tid, int lane) {
-    constexpr int N4 = 8 * (K + 4);
-    constexpr int NEXT_N4 = NEXT_K > 0 ? 8 * (NEXT_K + 4) : 0;
+    constexpr int N4 = slice_floats(K) / 4;
+    constexpr int NEXT_N4 = NEXT_K > 0 ? slice_floats(NEXT_K) / 4 : 0;
     const int h = lane >> 5;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -176,20 +181,13 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_train_kernel(const float *
     f32x16 out[8];
     const float *wp = packed;
     {
-        constexpr int N4 = 8 * (96 + 4), ROUNDS = (N4 + 255) / 256;
+        constexpr int ROUNDS = slice_floats(96) / 1024;
         f32x4 pf[ROUNDS];
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            int i4 = r * 256 + tid;
-            if (i4 > N4 - 1) i4 = N4 - 1;
-            pf[r] = *(const f32x4 *)(wp + 4 * (size_t)i4);
-        }
+        for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(wp + 4 * (size_t)(r * 256 + tid));
         load_features<8, 0, 3>(frow, h, Breg);
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int i4 = r * 256 + tid;
-            if ((r + 1) * 256 <= N4 || i4 < N4) *(f32x4 *)(lds + 4 * i4) = pf[r];
-        }
+        for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(lds + 4 * (r * 256 + tid)) = pf[r];
     }
     __syncthreads();
     const float *bias = packed;
@@ -242,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_train_kernel(const float *
 static FwdOffsets fwd_offsets() {
     FwdOffsets fo;
     int off = 0;
-    for (int l = 0; l < NLAYERS; ++l) off += kLayerNB[l] * 32 * (kLayerK[l] + 4);
+    for (int l = 0; l < NLAYERS; ++l) off += kLayerNB[l] * slice_floats(kLayerK[l]);
     for (int l = 0; l < NLAYERS; ++l) {
         fo.bias_off[l] = off;
         off += kLayerNB[l] * 32;
@@ -274,8 +272,8 @@ template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK>
 __device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *lds, const f32x16 (&Breg)[12],
                                          f32x16 (&out)[8], const float *__restrict__ acts, float *__restrict__ deltas,
                                          size_t ld, int row0, size_t col, int tid, int lane) {
-    constexpr int N4 = 8 * (K + 4);
-    constexpr int NEXT_N4 = NEXT_K > 0 ? 8 * (NEXT_K + 4) : 0;
+    constexpr int N4 = slice_floats(K) / 4;
+    constexpr int NEXT_N4 = NEXT_K > 0 ? slice_floats(NEXT_K) / 4 : 0;
     const int h = lane >> 5;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -314,14 +312,10 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_bwd_data_kernel(const float *_
     f32x16 out[8];
     const float *wp = packed_t;
     {
-        constexpr int N4 = 8 * (32 + 4), ROUNDS = (N4 + 255) / 256;
+        constexpr int ROUNDS = slice_floats(32) / 1024;
         f32x4 pf[ROUNDS];
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            int i4 = r * 256 + tid;
-            if (i4 > N4 - 1) i4 = N4 - 1;
-            pf[r] = *(const f32x4 *)(wp + 4 * (size_t)i4);
-        }
+        for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(wp + 4 * (size_t)(r * 256 + tid));
         // the d(raw) tile: tile row c = raw column c (rows 0..3 on lane half 0, rows 4,5 on lane half 1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Breg[8][r] = 0.0f;
@@ -338,10 +332,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_bwd_data_kernel(const float *_
             }
         }
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int i4 = r * 256 + tid;
-            if ((r + 1) * 256 <= N4 || i4 < N4) *(f32x4 *)(lds + 4 * i4) = pf[r];
-        }
+        for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(lds + 4 * (r * 256 + tid)) = pf[r];
     }
     __syncthreads();
     // d0: d(dir hidden) = heads^T d(raw), masked by relu'(dir hidden)            4 slices: buffers 0,1,0,1 -> next in 0

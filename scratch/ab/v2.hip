@@ -23,7 +23,7 @@
 // loop into lgkmcnt(0)); two stage buffers, one barrier per stage.
 #include <utility>
 
-#include "common.h"
+#include "/root/repo/ddnerf_amd/csrc/common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -23,7 +23,7 @@
 // loop into lgkmcnt(0)); two stage buffers, one barrier per stage.
 #include <utility>
 
-#include "common.h"
+#include "/root/repo/ddnerf_amd/csrc/common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -204,8 +204,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b, bool relu) {
     return __builtin_bit_cast(unsigned, r);
 }
 
-// One of the two B files (HA; this layer's / the next layer's activations ping-pong between HA and HB, 128
-// registers each) is homed in the accumulator half of the unified register file: MFMA reads its B operand from there directly, and the arch VGPRs stay free
+// The two B files (this layer's and the next layer's activations, 2 x 128 registers) are homed in the accumulator
+// half of the unified register file: MFMA reads its B operand from there directly, and the arch VGPRs stay free
 // for the accumulator tiles, the A ring and the VALU temporaries.  Left to itself hipcc keeps shuttling them
 // (5,600 v_accvgpr moves and 109 spills measured); defining every packed word through this one-instruction asm
 // gives it the AGPR register class from birth.
@@ -234,7 +234,7 @@ __device__ __forceinline__ const bf16x8 &bsrc(const bf16x8 (&H)[16], const bf16x
 // A fragments are read DEPTH k-steps ahead into a ring; the bias tile of block b+1 (its accumulators' start value,
 // shared by the column blocks) is read during block b; the bf16 re-pack of the previous block's tiles is placed
 // behind this block's first MFMAs; the next stage's weight pieces travel global -> VGPR -> LDS in the gaps.
-template <int KIND, int K, int NBLK, int B0, int NCONV, int DMA_BYTES, bool HN_AGPR>
+template <int KIND, int K, int NBLK, int B0, int NCONV, int DMA_BYTES>
 __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, const bf16x8 (&H)[NCOL][16],
                                               const bf16x8 (&X)[NCOL][8], bf16x8 (&Hn)[NCOL][16],
                                               f32x16 (&keep)[NCOL][2], bool relu, int lane, int wave,
@@ -266,20 +266,18 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
     auto piece_ok = [&](int i) { return (i + 1) * WG_WAVES <= PIECES || wave + WG_WAVES * i < PIECES; };
     auto ld_piece = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if (piece_ok(i)) pf[i % BF16_PFD] = *(const f32x4 *)(dma_src + (wave + WG_WAVES * i) * 1024 + lane * 16);
+        // EXP no load
     };
     auto st_piece = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if (piece_ok(i)) *(f32x4 *)(dma_dst + (wave + WG_WAVES * i) * 1024 + lane * 16) = pf[i % BF16_PFD];
+        // EXP no store
     };
     auto repack = [&](auto pbc, auto cc, auto qc) {  // quarter q of tile (block pb, column c) -> 2 packed pairs of Hn
         constexpr int pb = decltype(pbc)::value, c = decltype(cc)::value, q = decltype(qc)::value;
         if constexpr (B0 + pb < NCONV) {
             u32x4 w = __builtin_bit_cast(u32x4, Hn[c][2 * (B0 + pb) + q / 2]);
-            unsigned w0 = pack_bf16(acc[pb & 1][c][4 * q + 0], acc[pb & 1][c][4 * q + 1], relu);
-            unsigned w1 = pack_bf16(acc[pb & 1][c][4 * q + 2], acc[pb & 1][c][4 * q + 3], relu);
-            w[2 * (q & 1) + 0] = HN_AGPR ? to_agpr(w0) : w0;
-            w[2 * (q & 1) + 1] = HN_AGPR ? to_agpr(w1) : w1;
+            w[2 * (q & 1) + 0] = to_agpr(pack_bf16(acc[pb & 1][c][4 * q + 0], acc[pb & 1][c][4 * q + 1], relu));
+            w[2 * (q & 1) + 1] = to_agpr(pack_bf16(acc[pb & 1][c][4 * q + 2], acc[pb & 1][c][4 * q + 3], relu));
             Hn[c][2 * (B0 + pb) + q / 2] = __builtin_bit_cast(bf16x8, w);
         }
     };
@@ -301,12 +299,9 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
             if constexpr (i >= BF16_PFD) st_piece(std::integral_constant<int, (i >= BF16_PFD ? i - BF16_PFD : 0)>{});
             ld_piece(std::integral_constant<int, i>{});
         }
-        if constexpr (b > 0) {  // re-pack the previous block's tiles: 4 quarters x NCOL units spread over this block
-            static_for<4 * NCOL>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                if constexpr (1 + (u * (NKS - 2)) / (4 * NCOL) == ks)
-                    repack(std::integral_constant<int, b - 1>{}, std::integral_constant<int, u % NCOL>{},
-                           std::integral_constant<int, u / NCOL>{});
+        if constexpr (b > 0 && ks >= 1 && ks <= 4) {  // re-pack the previous block's tiles, a quarter per step
+            static_for<NCOL>([&](auto cc) {
+                repack(std::integral_constant<int, b - 1>{}, cc, std::integral_constant<int, ks - 1>{});
             });
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -325,7 +320,7 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
 
 // One layer = its stages.  On entry the layer's first stage sits in LDS buffer PAR (parked by the previous stage).
 // NEXT = layer whose first stage is fetched during this layer's last stage (-1: none).
-template <int L, int KIND, int NEXT, int PAR, int NCONV, bool HN_AGPR>
+template <int L, int KIND, int NEXT, int PAR, int NCONV>
 __device__ __forceinline__ void layer(const char *__restrict__ &wp, char *lds, const bf16x8 (&H)[NCOL][16],
                                       const bf16x8 (&X)[NCOL][8], bf16x8 (&Hn)[NCOL][16], f32x16 (&keep)[NCOL][2],
                                       bool relu, int wave, int lane) {
@@ -337,10 +332,10 @@ __device__ __forceinline__ void layer(const char *__restrict__ &wp, char *lds, c
         char *cur = lds + ((PAR + st) & 1) * STAGE_BYTES_MAX;
         char *nxt = lds + ((PAR + st + 1) & 1) * STAGE_BYTES_MAX;
         dma_wait();       // (only the prologue's LDS-DMA of the very first stage is ever pending here)
-        __syncthreads();  // every wave has parked its pieces of stage `st`; the other buffer is free again
+        // EXP: no barrier
         wp += stage_bytes(L, st);
         constexpr int nbytes = st + 1 < NST ? stage_bytes(L, st + 1) : (NEXT >= 0 ? stage_bytes(NEXT >= 0 ? NEXT : 0, 0) : 0);
-        stage_compute<KIND, K, nblk, first, NCONV, nbytes, HN_AGPR>(cur, H, X, Hn, keep, relu, lane, wave, wp, nxt);
+        stage_compute<KIND, K, nblk, first, NCONV, nbytes>(cur, H, X, Hn, keep, relu, lane, wave, wp, nxt);
     });
 }
 
@@ -374,22 +369,22 @@ __global__ __launch_bounds__(WG_THREADS, 1) void mlp_bf16_fwd_kernel(const unsig
 
     // parity of the LDS buffer holding a layer's first stage: L0 has 1 stage (buffer 0), every later layer has an
     // even number of stages and starts in buffer 1
-    layer<0, 0, 1, 0, 8, true>(wp, lds, HA, X, HA, keep, true, wave, lane);    // 96 -> 256            (H unused: KIND 0)
-    layer<1, 1, 2, 1, 8, false>(wp, lds, HA, X, HB, keep, true, wave, lane);
-    layer<2, 1, 3, 1, 8, true>(wp, lds, HB, X, HA, keep, true, wave, lane);
-    layer<3, 1, 4, 1, 8, false>(wp, lds, HA, X, HB, keep, true, wave, lane);
-    layer<4, 1, 5, 1, 8, true>(wp, lds, HB, X, HA, keep, true, wave, lane);
+    layer<0, 0, 1, 0, 8>(wp, lds, HA, X, HA, keep, true, wave, lane);    // 96 -> 256            (H unused: KIND 0)
+    layer<1, 1, 2, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);
+    layer<2, 1, 3, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
+    layer<3, 1, 4, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);
+    layer<4, 1, 5, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
     load_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
-    layer<5, 2, 6, 1, 8, false>(wp, lds, HA, X, HB, keep, true, wave, lane);    // cat(xyz, h) 352 -> 256, 4 stages
-    layer<6, 1, 7, 1, 8, true>(wp, lds, HB, X, HA, keep, true, wave, lane);
-    layer<7, 1, 8, 1, 8, false>(wp, lds, HA, X, HB, keep, true, wave, lane);
-    layer<8, 1, 9, 1, 8, true>(wp, lds, HB, X, HA, keep, false, wave, lane);   // fc_feat: no activation
+    layer<5, 2, 6, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);    // cat(xyz, h) 352 -> 256, 4 stages
+    layer<6, 1, 7, 1, 8>(wp, lds, HB, X, HA, keep, true, wave, lane);
+    layer<7, 1, 8, 1, 8>(wp, lds, HA, X, HB, keep, true, wave, lane);
+    layer<8, 1, 9, 1, 8>(wp, lds, HB, X, HA, keep, false, wave, lane);   // fc_feat: no activation
     load_x(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});  // view-dir columns
-    layer<9, 3, 10, 1, 4, false>(wp, lds, HA, X, HB, keep, true, wave, lane);   // dir layer (128, ReLU) + alpha row
+    layer<9, 3, 10, 1, 4>(wp, lds, HA, X, HB, keep, true, wave, lane);   // dir layer (128, ReLU) + alpha row
     float alpha[NCOL];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) alpha[c] = keep[c][0][0];             // row 128 = block 4, register 0, lane half 0
-    layer<10, 4, -1, 1, 0, true>(wp, lds, HB, X, HA, keep, false, wave, lane);  // heads
+    layer<10, 4, -1, 1, 0>(wp, lds, HB, X, HA, keep, false, wave, lane);  // heads
 
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
