@@ -90,22 +90,27 @@ def cpu_baseline(args, cfg, sd_c, sd_f):
     import oracle as O
     from ddnerf_amd import synthetic
 
-    n = args.cpu_rays
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(threads, int(os.environ.get("DDNERF_CPU_THREADS", "64")))
     O.set_threads(threads)
-    ro, rd, rad, _ = synthetic.make_rays("blender", n, 1)
     t_lin = torch.linspace(0.0, 1.0, args.coarse + 1).numpy()
     u_det = torch.linspace(0.0, 0.9999, args.fine + 1).numpy()
-    rng = np.random.default_rng(0)
-    kw = dict(model="dd", nc=args.coarse, nf=args.fine, near=2.0, far=6.0, blender=True, pdf_padding=True, smooth=1.7,
-              dist_reg=float(cfg.train_params.dist_reg_coeficient), t_lin=t_lin, u_det=u_det,
-              noise0=rng.standard_normal((n, args.coarse)).astype(np.float32),
-              noise1=rng.standard_normal((n, args.fine)).astype(np.float32))
-    O.run_iter(ro[:16], rd[:16], rad[:16], sd_c, sd_f, **dict(kw, noise0=kw["noise0"][:16], noise1=kw["noise1"][:16]))
-    t0 = time.perf_counter()
-    O.run_iter(ro, rd, rad, sd_c, sd_f, **kw)
-    dt = time.perf_counter() - t0
+
+    def run(n):
+        ro, rd, rad, _ = synthetic.make_rays("blender", n, 1)
+        rng = np.random.default_rng(0)
+        kw = dict(model="dd", nc=args.coarse, nf=args.fine, near=2.0, far=6.0, blender=True, pdf_padding=True,
+                  smooth=1.7, dist_reg=float(cfg.train_params.dist_reg_coeficient), t_lin=t_lin, u_det=u_det,
+                  noise0=rng.standard_normal((n, args.coarse)).astype(np.float32),
+                  noise1=rng.standard_normal((n, args.fine)).astype(np.float32))
+        t0 = time.perf_counter()
+        O.run_iter(ro, rd, rad, sd_c, sd_f, **kw)
+        return time.perf_counter() - t0
+
+    run(64)                                  # warm-up (thread pool, page faults)
+    probe = run(args.cpu_rays)               # calibrate, then size the sample for ~15 s of CPU work
+    n = int(min(max(args.cpu_rays, args.cpu_rays * 15.0 / max(probe, 1e-3)), 65536)) // 256 * 256
+    dt = run(n)
     return {"value": n / dt, "unit": "rays/s", "cores": O.get_threads(), "kind": "port",
             "sample": "%d rays x (%d+%d) samples, render pass, C oracle with OpenMP, %.1f s" % (n, args.coarse, args.fine, dt)}
 
@@ -171,11 +176,16 @@ def main():
         M_fine = args.rays * args.fine
         ms, launches = timer.mean_ms(M_fine)
         roof = None
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s.json" % args.mlp)
+        if os.path.exists(tf) and args.mode == "render" and (args.rays, args.fine) == (4096, 128):
+            # HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (see the file)
+            traffic = json.load(open(tf)).get("fine_mlp_%s_fwd_hbm_bytes_per_launch" % args.mlp)
         if ms:
             ach = M_fine * FLOP_FINE / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "mlp_%s_fwd_kernel<fine> (%d samples/launch)" % (args.mlp, M_fine),
                     "achieved": round(ach, 2), "peak": PEAK[args.mlp], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK[args.mlp], 4), "traffic": None, "launch_ms": round(ms, 4),
+                    "frac": round(ach / PEAK[args.mlp], 4), "traffic": traffic, "launch_ms": round(ms, 4),
                     "launches_timed": launches}
         line = {
             "metric": "rays/sec (4096 rays x 128 samples, 8x256 MLP)",

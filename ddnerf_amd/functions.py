@@ -13,18 +13,18 @@ import torch
 from . import ops
 
 # ---- MLP -------------------------------------------------------------------------------------------------
-_pack_cache = {}
-
-
 def _cached_pack(net, kind, builder):
+    """kernel-format weights, repacked only when the flat parameter buffer changed (optimizer step, load_state_dict).
+    The cache lives ON the module: a global table keyed by id(net) would hand a new model the packed weights of a
+    garbage-collected one that happened to get the same id and buffer address."""
     flat = net.flat_params()
-    key = (id(net), kind)
+    cache = net.__dict__.setdefault("_packed_cache", {})
     tag = (flat.data_ptr(), flat._version)
-    hit = _pack_cache.get(key)
+    hit = cache.get(kind)
     if hit is not None and hit[0] == tag:
         return hit[1]
     packed = builder(flat, net.depth_head)
-    _pack_cache[key] = (tag, packed)
+    cache[kind] = (tag, packed)
     return packed
 
 
