@@ -26,33 +26,6 @@ __device__ __forceinline__ constexpr int bsel(int q) {
                      : q / 4;
 }
 
-// one 32-row slice: acc(32 out-features x 32 samples) += W_slice * B.
-// One wave per SIMD means nothing else hides the LDS latency: the A fragments are read two chunks
-// (8 MFMAs = 512 cycles) ahead of their use.
-template <int KIND, int K>
-__device__ __forceinline__ void slice_mfma(const float *__restrict__ buf, const f32x16 (&Breg)[12], f32x16 &acc,
-                                           int lane) {
-    constexpr int NQ = K / 8;
-    const float *a_row = buf + (lane & 31) * (K + 4) + 4 * (lane >> 5);
-    f32x4 a[NQ];
-    a[0] = *(const f32x4 *)(a_row);
-    a[1] = *(const f32x4 *)(a_row + 8);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (q + 2 < NQ) a[q + 2] = *(const f32x4 *)(a_row + 8 * (q + 2));
-        // pin the emitted order: 4 MFMAs, then the DS read that runs two chunks ahead (cdna guide T19)
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        const int blk = bsel<KIND>(q);
-        const int g = (KIND == 2 && q >= 12) ? (q - 12) % 4 : q % 4;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, Breg[blk][4 * g + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, Breg[blk][4 * g + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, Breg[blk][4 * g + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, Breg[blk][4 * g + 3], acc, 0, 0, 0);
-    }
-}
-
 __device__ __forceinline__ f32x16 bias_tile(const float *__restrict__ bias32, int h) {
     f32x16 v;
 #pragma unroll
@@ -81,16 +54,34 @@ __device__ __forceinline__ void slice_step_hooks(const float *__restrict__ next_
                                                  const f32x16 (&Breg)[12], f32x16 &acc, int tid, int lane, Init &&init,
                                                  Post &&post) {
     static_assert(PF_N4 % 256 == 0, "slices are padded to whole copy rounds");
-    constexpr int ROUNDS = PF_N4 / 256;
+    constexpr int ROUNDS = PF_N4 / 256, NQ = K / 8, R2 = ROUNDS > 0 ? 2 * ROUNDS : 1;
     f32x4 pf[ROUNDS > 0 ? ROUNDS : 1];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(next_src + 4 * (size_t)(r * 256 + tid));
+    f32x4 a[NQ];
+    // The statement order below IS the schedule (one wave per SIMD: nothing else hides latencies), pinned with a
+    // sched_barrier(0) per chunk: the A fragments are read two chunks (8 MFMAs = 512 cycles) ahead; the next slice's
+    // copy rounds are fetched (global -> registers) behind the MFMAs of the first half of the slice and parked in the
+    // other LDS buffer behind those of the second half, so neither sits in front of the first or after the last MFMA.
+    const float *a_row = cur + (lane & 31) * (K + 4) + 4 * (lane >> 5);
+    a[0] = *(const f32x4 *)(a_row);
+    a[1] = *(const f32x4 *)(a_row + 8);
     init(acc);
-    __builtin_amdgcn_sched_barrier(0);  // keep the fetches ABOVE the MFMA block: their latency hides under it
-    slice_mfma<KIND, K>(cur, Breg, acc, lane);
-    __builtin_amdgcn_sched_barrier(0);  // and the LDS commit BELOW it
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(nxt + 4 * (r * 256 + tid)) = pf[r];
+    for (int q = 0; q < NQ; ++q) {
+        const int blk = bsel<KIND>(q);
+        const int g = (KIND == 2 && q >= 12) ? (q - 12) % 4 : q % 4;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, Breg[blk][4 * g + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, Breg[blk][4 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, Breg[blk][4 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, Breg[blk][4 * g + 3], acc, 0, 0, 0);
+        if (q + 2 < NQ) a[q + 2] = *(const f32x4 *)(a_row + 8 * (q + 2));
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if ((r * NQ) / R2 == q) pf[r] = *(const f32x4 *)(next_src + 4 * (size_t)(r * 256 + tid));
+            if (NQ / 2 + (r * NQ) / R2 == q) *(f32x4 *)(nxt + 4 * (r * 256 + tid)) = pf[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     post(acc);
     __syncthreads();
 }
