@@ -39,6 +39,9 @@ _SIGS = {
     "ddnerf_mlp_f32_backward_data": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_ray_bundle": (C.c_int, [C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "ddnerf_mlp_f32_wgrad_workspace_floats": (C.c_size_t, [C.c_long]),
+    "ddnerf_mlp_f32_wgrad": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
+                                       C.c_int, C.c_int, c_fp, c_fp, c_fp]),
 }
 
 _lib = None

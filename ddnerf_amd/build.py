@@ -22,6 +22,7 @@ SOURCES = {
     "raygen.hip": EXACT,
     "mlp_f32.hip": [],
     "mlp_f32_train.hip": [],
+    "mlp_f32_wgrad.hip": [],
     # accumulators in arch VGPRs (the VALU re-pack reads them), B files in the accumulator half: see mlp_bf16.hip
     "mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }

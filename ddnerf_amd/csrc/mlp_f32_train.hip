@@ -8,16 +8,20 @@
 //   * backward_data: ONE fused kernel chains d(raw) back through all layers exactly like the forward chains
 //     activations -- delta_l^T = (W_{l+1}^T delta_{l+1}^T) * relu'(h_l), the accumulator tile of one step is the B
 //     operand of the next, deltas never leave registers between layers -- and stores every delta transposed too.
-//   * weight gradients dW_l = delta_l^T (h_{l-1}^T)^T are then plain GEMMs over the sample axis on the two stored
-//     [feature][sample] matrices (both operands K-contiguous): handed to the BLAS library by the host (ops.py),
-//     as are the bias gradients (row sums).
+//   * weight gradients dW_l = delta_l^T (h_{l-1}^T)^T contract over the sample axis of the two stored
+//     [feature][sample] matrices (both operands K-contiguous): mlp_f32_wgrad.hip (split over the samples, order-fixed
+//     reduce), which also produces the bias gradients (row sums).
 // Row map of `acts` and `deltas` (ld = samples rounded up to 128):
 //   rows 256*l .. 256*l+255 : layers_xyz.l output (post-ReLU) / its pre-activation gradient,   l = 0..7
 //   rows 2048 .. 2303       : fc_feat output (no activation)  / its gradient
 //   rows 2304 .. 2431       : layers_dir.0 output (post-ReLU) / its pre-activation gradient
+//   rows 2432 .. 2559       : acts: the input features (xyz 0..95, view dirs 96..122, zeros), transposed, so the first-layer /
+//                             skip / dir weight gradients contract over contiguous samples too;
+//                             deltas: rows 2432..2437 = d(raw) columns 0..5 transposed (head weight gradients)
 #include "mlp_f32_common.h"
 
-#define ACT_ROWS 2432
+#define ACT_ROWS 2560
+#define ROW_X 2432  // acts: the 128 input feature columns, transposed; deltas: the d(raw) tile (rows 0..5 used)
 #define ROW_FEAT 2048
 #define ROW_DIR 2304
 
@@ -187,6 +191,8 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_train_kernel(const float *
         for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(wp + 4 * (size_t)(r * 256 + tid));
         load_features<8, 0, 3>(frow, h, Breg);
 #pragma unroll
+        for (int b = 0; b < 3; ++b) store_tile_t(acts, ld, ROW_X + 32 * b, m, h, Breg[8 + b]);
+#pragma unroll
         for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(lds + 4 * (r * 256 + tid)) = pf[r];
     }
     __syncthreads();
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_train_kernel(const float *
 #pragma unroll
     for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     load_features<11, 3, 1>(frow, h, Breg);
+    store_tile_t(acts, ld, ROW_X + 96, m, h, Breg[11]);
     __builtin_amdgcn_sched_barrier(0);
     layer_fwd_train<3, 288, 5, 128, 0, true, 4>(wp, bias + fo.bias_off[9], lds, Breg, out, acts, ld, ROW_DIR, m, tid, lane);
     const float alpha = out[4][0];
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_bwd_data_kernel(const float *_
                 Breg[8][1] = g[5];
             }
         }
+        store_tile_t(deltas, ld, ROW_X, m, h, Breg[8]);
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(lds + 4 * (r * 256 + tid)) = pf[r];
     }

@@ -41,53 +41,6 @@ def _forward_kernel(feat, net):
     return ops.mlp_bf16_forward(feat, packed, net.depth_head)
 
 
-def mlp_weight_grads(net, feat, acts, deltas, g_raw):
-    """dW_l = delta_l^T (input_l)^T over the sample axis -- plain GEMMs on the two transposed [feature][sample]
-    matrices the fused kernels stored (handed to the BLAS library); bias gradients are row sums.
-    Returns the flat gradient buffer (registration order) and its per-parameter views."""
-    M = feat.shape[0]
-    params = list(net.parameters())
-    flat_g = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=feat.device)
-    views, off = [], 0
-    for p in params:
-        views.append(flat_g[off:off + p.numel()].view(p.shape))
-        off += p.numel()
-    gv = {name: v for (name, _), v in zip(net.named_parameters(), views)}
-    A = lambda r0, rows: acts[r0:r0 + rows, :M]      # [rows, M] (row = feature)
-    D = lambda r0, rows: deltas[r0:r0 + rows, :M]
-    x_xyz, x_dir = feat[:, :96], feat[:, 96:123]      # [M, 96], [M, 27] (row = sample)
-    for l in range(8):
-        d = D(256 * l, 256)
-        w = gv["layers_xyz.%d.weight" % l]
-        if l == 0:
-            torch.mm(d, x_xyz, out=w)
-        elif l == 5:
-            w[:, :96] = torch.mm(d, x_xyz)
-            w[:, 96:] = torch.mm(d, A(256 * 4, 256).t())
-        else:
-            torch.mm(d, A(256 * (l - 1), 256).t(), out=w)
-        torch.sum(d, dim=1, out=gv["layers_xyz.%d.bias" % l])
-    d_feat, d_dir = D(ops.ROW_FEAT, 256), D(ops.ROW_DIR, 128)
-    a_feat, a_dir = A(ops.ROW_FEAT, 256), A(ops.ROW_DIR, 128)
-    torch.mm(d_feat, A(256 * 7, 256).t(), out=gv["fc_feat.weight"])
-    torch.sum(d_feat, dim=1, out=gv["fc_feat.bias"])
-    g_alpha = g_raw[:, 3]
-    torch.mv(a_feat, g_alpha, out=gv["fc_alpha.weight"].view(-1))
-    gv["fc_alpha.bias"].copy_(g_alpha.sum().reshape(1))
-    wd = gv["layers_dir.0.weight"]
-    wd[:, :256] = torch.mm(d_dir, a_feat.t())
-    wd[:, 256:] = torch.mm(d_dir, x_dir)
-    torch.sum(d_dir, dim=1, out=gv["layers_dir.0.bias"])
-    g_rgb = g_raw[:, :3]
-    torch.mm(g_rgb.t(), a_dir.t(), out=gv["fc_rgb.weight"])
-    torch.sum(g_rgb, dim=0, out=gv["fc_rgb.bias"])
-    if net.depth_head:
-        g_ms = g_raw[:, 4:6]
-        torch.mm(g_ms.t(), a_dir.t(), out=gv["fc_mu_sigma.weight"])
-        torch.sum(g_ms, dim=0, out=gv["fc_mu_sigma.bias"])
-    return flat_g, views
-
-
 class _MLPFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, net, *params):
@@ -107,7 +60,7 @@ class _MLPFunction(torch.autograd.Function):
         g_raw = g_raw.contiguous()
         packed_t = _cached_pack(net, "fp32_t", ops.mlp_f32_pack_t)
         deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head)
-        flat_g, views = mlp_weight_grads(net, feat, acts, deltas, g_raw)
+        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0])
         net.last_flat_grad = flat_g  # the data-parallel bucket (ddnerf_amd.dist) reduces this buffer
         reducer = getattr(net, "grad_reducer", None)
         if reducer is not None:

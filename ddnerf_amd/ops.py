@@ -227,8 +227,8 @@ def dp_loss_backward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender, g_loss):
     return gw, gm, gs
 
 
-ACT_ROWS = 2432
-ROW_FEAT, ROW_DIR = 2048, 2304
+ACT_ROWS = 2560
+ROW_FEAT, ROW_DIR, ROW_X = 2048, 2304, 2432
 
 
 def mlp_f32_pack_t(params_flat, depth_head):
@@ -291,3 +291,43 @@ def ndc_rays(H, W, focal, origins, directions, near=1.0):
     _lib.check(_lib.lib().ddnerf_ndc_rays(int(H), int(W), float(focal), float(near), _ptr(origins), _ptr(directions), _ptr(o),
                                           _ptr(d), _ptr(r), _stream()), "ddnerf_ndc_rays")
     return o, d, r
+
+
+def mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, dst, dst_ld, dst_col0, dst_bias, workspace):
+    """dst[r*dst_ld + dst_col0 + c] = sum_s deltas[drow0+r][s] * acts[arow0+c][s]; dst_bias[r] = sum_s deltas[drow0+r][s]"""
+    _lib.check(_lib.lib().ddnerf_mlp_f32_wgrad(_ptr(deltas), drow0, n_out, _ptr(acts), arow0, n_in, n_in_used, M,
+                                               deltas.shape[1], _ptr(dst), dst_ld, dst_col0, _ptr(dst_bias),
+                                               _ptr(workspace), _stream()), "ddnerf_mlp_f32_wgrad")
+
+
+def mlp_f32_weight_grads(net, acts, deltas, M):
+    """all parameter gradients of one network -> (flat gradient buffer in registration order, per-parameter views)"""
+    params = list(net.parameters())
+    flat_g = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=acts.device)
+    off, gv, views = 0, {}, []
+    for (name, p) in net.named_parameters():
+        v = flat_g[off:off + p.numel()].view(p.shape)
+        gv[name] = v
+        views.append(v)
+        off += p.numel()
+    ws = torch.empty(_lib.lib().ddnerf_mlp_f32_wgrad_workspace_floats(M), dtype=torch.float32, device=acts.device)
+    job = lambda *a: mlp_f32_wgrad_job(deltas, a[0], a[1], acts, a[2], a[3], a[4], M, a[5], a[6], a[7], a[8], ws)
+    for l in range(8):
+        w, b = gv["layers_xyz.%d.weight" % l], gv["layers_xyz.%d.bias" % l]
+        if l == 0:
+            job(0, 256, ROW_X, 96, 96, w, 96, 0, b)
+        elif l == 5:
+            job(1280, 256, ROW_X, 96, 96, w, 352, 0, b)
+            job(1280, 256, 1024, 256, 256, w, 352, 96, None)
+        else:
+            job(256 * l, 256, 256 * (l - 1), 256, 256, w, 256, 0, b)
+    job(ROW_FEAT, 256, 256 * 7, 256, 256, gv["fc_feat.weight"], 256, 0, gv["fc_feat.bias"])
+    wd = gv["layers_dir.0.weight"]
+    job(ROW_DIR, 128, ROW_FEAT, 256, 256, wd, 283, 0, gv["layers_dir.0.bias"])
+    job(ROW_DIR, 128, ROW_X + 96, 32, 27, wd, 283, 256, None)
+    # heads: d(raw) rows 0..2 rgb, 3 alpha, 4..5 mu/sigma (deltas rows ROW_X..)
+    job(ROW_X, 3, ROW_DIR, 128, 128, gv["fc_rgb.weight"], 128, 0, gv["fc_rgb.bias"])
+    job(ROW_X + 3, 1, ROW_FEAT, 256, 256, gv["fc_alpha.weight"], 256, 0, gv["fc_alpha.bias"])
+    if net.depth_head:
+        job(ROW_X + 4, 2, ROW_DIR, 128, 128, gv["fc_mu_sigma.weight"], 128, 0, gv["fc_mu_sigma.bias"])
+    return flat_g, views

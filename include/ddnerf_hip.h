@@ -167,8 +167,11 @@ int ddnerf_dp_loss_backward(const float *t1, const float *t0, const float *w1, c
  *   forward_train : forward + records every layer's output in `acts`
  *   pack_t        : transposed weight images for the backward-data kernel (once per weight update)
  *   backward_data : g_raw [M,4|6] -> every layer's pre-activation gradient in `deltas` (one fused kernel)
- * Weight gradients are then the plain GEMMs  dW_l = deltas[rows of l] x acts[rows of l-1]^T  over the sample axis
- * (bias gradients: row sums), left to the BLAS library on the host side. */
+ *   wgrad         : one weight-gradient job dW = deltas[drow0:+n_out] x acts[arow0:+n_in]^T over the sample axis on the
+ *                   fp32 matrix cores, split over the samples with an order-fixed second-stage reduce (no atomics);
+ *                   bias gradient = row sums of the delta rows.  rows 2432.. of `acts` hold the input features
+ *                   transposed, rows 2432..2437 of `deltas` hold d(raw) transposed (head layers).
+ * Row count of both matrices: ddnerf_mlp_act_rows(). */
 size_t ddnerf_mlp_act_rows(void);
 size_t ddnerf_mlp_f32_packed_t_floats(int depth_head);
 int ddnerf_mlp_f32_pack_t(const float *params, int depth_head, float *packed_t, ddnerf_stream_t stream);
@@ -176,6 +179,10 @@ int ddnerf_mlp_f32_forward_train(const float *feat, const float *packed, int dep
                                  long ld, ddnerf_stream_t stream);
 int ddnerf_mlp_f32_backward_data(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
                                  float *deltas, long M, long ld, ddnerf_stream_t stream);
+size_t ddnerf_mlp_f32_wgrad_workspace_floats(long M);
+int ddnerf_mlp_f32_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,
+                         long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
+                         ddnerf_stream_t stream);
 
 #ifdef __cplusplus
 }
