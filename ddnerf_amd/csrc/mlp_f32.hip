@@ -141,8 +141,8 @@ __device__ __forceinline__ void layer(const float *__restrict__ &wp, const float
             if (b + 1 < NB) bnext = bias_tile(bias + 32 * (b + 1), h);
         };
         auto post = [](f32x16 &) {};
-        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
-        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, [](int, int) {}, post);
+        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, [](int, int) {}, post);
         if (b + 1 < NB) bcur = bnext;
     }
 }

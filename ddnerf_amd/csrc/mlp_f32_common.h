@@ -48,11 +48,12 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 // One slice step: fetch the NEXT slice (PF_N4 float4 pieces, 0 = nothing to fetch) into registers, multiply the
 // current one out of LDS, then park the fetched slice in the other LDS buffer; one barrier.
 //   init(acc)  -- accumulator start value (bias tile / zero) and any loads whose latency should hide under the MFMAs
+//   mid(q, NQ) -- runs inside MFMA chunk q of NQ (work to spread behind the MFMAs: stores of the previous tile)
 //   post(acc)  -- runs after the slice's MFMAs (activation, stores of activations / deltas)
-template <int KIND, int K, int PF_N4, class Init, class Post>
+template <int KIND, int K, int PF_N4, class Init, class Mid, class Post>
 __device__ __forceinline__ void slice_step_hooks(const float *__restrict__ next_src, const float *cur, float *nxt,
                                                  const f32x16 (&Breg)[12], f32x16 &acc, int tid, int lane, Init &&init,
-                                                 Post &&post) {
+                                                 Mid &&mid, Post &&post) {
     static_assert(PF_N4 % 256 == 0, "slices are padded to whole copy rounds");
     constexpr int ROUNDS = PF_N4 / 256, NQ = K / 8, R2 = ROUNDS > 0 ? 2 * ROUNDS : 1;
     f32x4 pf[ROUNDS > 0 ? ROUNDS : 1];
@@ -80,6 +81,7 @@ __device__ __forceinline__ void slice_step_hooks(const float *__restrict__ next_
             if ((r * NQ) / R2 == q) pf[r] = *(const f32x4 *)(next_src + 4 * (size_t)(r * 256 + tid));
             if (NQ / 2 + (r * NQ) / R2 == q) *(f32x4 *)(nxt + 4 * (r * 256 + tid)) = pf[r];
         }
+        mid(q, NQ);
         __builtin_amdgcn_sched_barrier(0);
     }
     post(acc);
@@ -91,7 +93,7 @@ __device__ __forceinline__ void slice_step(const float *__restrict__ next_src, c
                                            const float *cur, float *nxt, const f32x16 (&Breg)[12], f32x16 &acc,
                                            int tid, int lane) {
     slice_step_hooks<KIND, K, PF_N4>(
-        next_src, cur, nxt, Breg, acc, tid, lane, [&](f32x16 &a) { a = bias_tile(bias32, lane >> 5); },
+        next_src, cur, nxt, Breg, acc, tid, lane, [&](f32x16 &a) { a = bias_tile(bias32, lane >> 5); }, [](int, int) {},
         [](f32x16 &) {});
 }
 

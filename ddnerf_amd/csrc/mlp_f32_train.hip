@@ -112,16 +112,20 @@ DDN_EXPORT int ddnerf_mlp_f32_pack_t(const float *params, int depth_head, float 
     return ddn_launch_status();
 }
 
+#define TADDR(row, ld, col) ((size_t)(row) * (ld) + (col))
+// streaming data is written / read non-temporally: it must not evict the weight slices every block re-reads from L2
+#define TSTORE(v, p) __builtin_nontemporal_store(v, p)
+#define TLOAD(p) __builtin_nontemporal_load(p)
 // ---- shared: store / load one accumulator tile in the transposed [feature][sample] matrices -------------------
 __device__ __forceinline__ void store_tile_t(float *__restrict__ mat, size_t ld, int row0, size_t col, int h,
                                              const f32x16 &v) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mat[(size_t)(row0 + tile_row(r, h)) * ld + col] = v[r];
+    for (int r = 0; r < 16; ++r) TSTORE(v[r], &mat[TADDR(row0 + tile_row(r, h), ld, col)]);
 }
 __device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, size_t ld, int row0, size_t col, int h) {
     f32x16 v;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = mat[(size_t)(row0 + tile_row(r, h)) * ld + col];
+    for (int r = 0; r < 16; ++r) v[r] = TLOAD(&mat[TADDR(row0 + tile_row(r, h), ld, col)]);
     return v;
 }
 
@@ -142,8 +146,12 @@ __device__ __forceinline__ void load_features(const float *__restrict__ frow, in
 
 // ---- forward that records activations -----------------------------------------------------------------------
 // One layer: as in mlp_f32.hip, plus: ReLU applied per tile and the tile stored to acts rows [ROW0 + 32 b ...].
+// vmcnt retires in order and counts stores too, so nothing a step waits for may be issued right after the previous
+// tile's 16 stores: every bias tile (the next layer's first one included, `next_bias`) is fetched one step ahead
+// (`bcur` carries it across steps and layers), and the weight fetches wait half a slice after they were issued.
 template <int KIND, int K, int NB, int NEXT_K, int PAR, bool RELU, int NSTORE>
-__device__ __forceinline__ void layer_fwd_train(const float *__restrict__ &wp, const float *__restrict__ bias, float *lds,
+__device__ __forceinline__ void layer_fwd_train(const float *__restrict__ &wp, const float *__restrict__ bias,
+                                                const float *__restrict__ next_bias, f32x16 &bcur, float *lds,
                                                 const f32x16 (&Breg)[12], f32x16 (&out)[8], float *__restrict__ acts,
                                                 size_t ld, int row0, size_t col, int tid, int lane) {
     constexpr int N4 = slice_floats(K) / 4;
@@ -154,15 +162,23 @@ __device__ __forceinline__ void layer_fwd_train(const float *__restrict__ &wp, c
         const float *cur = lds + ((PAR + b) & 1) * MAX_SLICE_FLOATS;
         float *nxt = lds + ((PAR + b + 1) & 1) * MAX_SLICE_FLOATS;
         wp += 4 * N4;
-        auto init = [&](f32x16 &a) { a = bias_tile(bias + 32 * b, h); };
+        f32x16 bnext;
+        auto init = [&](f32x16 &a) {
+            a = bcur;
+            if (b + 1 < NB) bnext = bias_tile(bias + 32 * (b + 1), h);
+            else if (NEXT_K > 0) bnext = bias_tile(next_bias, h);
+        };
+        // (deferring the epilogue of tile b-1 into the MFMA chunks of tile b was measured SLOWER: 5.12 vs 5.04 ms)
+        auto mid = [](int, int) {};
         auto post = [&](f32x16 &a) {
             if (b < NSTORE) {
                 if (RELU) a = relu16(a);
                 store_tile_t(acts, ld, row0 + 32 * b, col, h, a);
             }
         };
-        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
-        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, mid, post);
+        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, mid, post);
+        if (b + 1 < NB || NEXT_K > 0) bcur = bnext;
     }
 }
 
@@ -197,38 +213,39 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_train_kernel(const float *
     }
     __syncthreads();
     const float *bias = packed;
-    layer_fwd_train<0, 96, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[0], lds, Breg, out, acts, ld, 0, m, tid, lane);
+    f32x16 bcur = bias_tile(bias + fo.bias_off[0], h);
+    layer_fwd_train<0, 96, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[0], bias + fo.bias_off[1], bcur, lds, Breg, out, acts, ld, 0, m, tid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     for (int l = 1; l <= 3; ++l) {
-        layer_fwd_train<1, 256, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[l], lds, Breg, out, acts, ld, 256 * l, m, tid, lane);
+        layer_fwd_train<1, 256, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[l], bias + fo.bias_off[l + 1], bcur, lds, Breg, out, acts, ld, 256 * l, m, tid, lane);
 #pragma unroll
         for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     }
-    layer_fwd_train<1, 256, 8, 352, 0, true, 8>(wp, bias + fo.bias_off[4], lds, Breg, out, acts, ld, 256 * 4, m, tid, lane);
+    layer_fwd_train<1, 256, 8, 352, 0, true, 8>(wp, bias + fo.bias_off[4], bias + fo.bias_off[5], bcur, lds, Breg, out, acts, ld, 256 * 4, m, tid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     load_features<8, 0, 3>(frow, h, Breg);
     __builtin_amdgcn_sched_barrier(0);
-    layer_fwd_train<2, 352, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[5], lds, Breg, out, acts, ld, 256 * 5, m, tid, lane);
+    layer_fwd_train<2, 352, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[5], bias + fo.bias_off[6], bcur, lds, Breg, out, acts, ld, 256 * 5, m, tid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     for (int l = 6; l <= 7; ++l) {
-        layer_fwd_train<1, 256, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[l], lds, Breg, out, acts, ld, 256 * l, m, tid, lane);
+        layer_fwd_train<1, 256, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[l], bias + fo.bias_off[l + 1], bcur, lds, Breg, out, acts, ld, 256 * l, m, tid, lane);
 #pragma unroll
         for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     }
-    layer_fwd_train<1, 256, 8, 288, 0, false, 8>(wp, bias + fo.bias_off[8], lds, Breg, out, acts, ld, ROW_FEAT, m, tid, lane);
+    layer_fwd_train<1, 256, 8, 288, 0, false, 8>(wp, bias + fo.bias_off[8], bias + fo.bias_off[9], bcur, lds, Breg, out, acts, ld, ROW_FEAT, m, tid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     load_features<11, 3, 1>(frow, h, Breg);
     store_tile_t(acts, ld, ROW_X + 96, m, h, Breg[11]);
     __builtin_amdgcn_sched_barrier(0);
-    layer_fwd_train<3, 288, 5, 128, 0, true, 4>(wp, bias + fo.bias_off[9], lds, Breg, out, acts, ld, ROW_DIR, m, tid, lane);
+    layer_fwd_train<3, 288, 5, 128, 0, true, 4>(wp, bias + fo.bias_off[9], bias + fo.bias_off[10], bcur, lds, Breg, out, acts, ld, ROW_DIR, m, tid, lane);
     const float alpha = out[4][0];
 #pragma unroll
     for (int b = 0; b < 4; ++b) Breg[b] = out[b];
-    layer_fwd_train<4, 128, 1, 0, 1, false, 0>(wp, bias + fo.bias_off[10], lds, Breg, out, acts, ld, 0, m, tid, lane);
+    layer_fwd_train<4, 128, 1, 0, 1, false, 0>(wp, bias + fo.bias_off[10], bias, bcur, lds, Breg, out, acts, ld, 0, m, tid, lane);
     if (valid) {
         if (DEPTH) {
             float *o = raw + (size_t)m * 6;
@@ -273,8 +290,8 @@ DDN_EXPORT int ddnerf_mlp_f32_forward_train(const float *feat, const float *pack
 }
 
 // ---- fused backward-data ------------------------------------------------------------------------------------
-// One backward step: NB tiles of the outgoing delta.  MASK_ROW0 >= 0: multiply by relu'(acts rows) (the tile of the
-// recorded activation is fetched before the MFMAs of its slice so that its latency hides under them).
+// One backward step: NB tiles of the outgoing delta.  MASK: multiply by relu'(recorded activation), whose tile is
+// requested at the start of its slice and used a whole slice later.
 template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK>
 __device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *lds, const f32x16 (&Breg)[12],
                                          f32x16 (&out)[8], const float *__restrict__ acts, float *__restrict__ deltas,
@@ -293,6 +310,7 @@ __device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *l
             for (int r = 0; r < 16; ++r) a[r] = 0.0f;
             if (MASK) act = load_tile_t(acts, ld, row0 + 32 * b, col, h);
         };
+        auto mid = [](int, int) {};
         auto post = [&](f32x16 &a) {
             if (MASK) {
 #pragma unroll
@@ -300,8 +318,8 @@ __device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *l
             }
             store_tile_t(deltas, ld, row0 + 32 * b, col, h, a);
         };
-        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
-        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, post);
+        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, mid, post);
+        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, mid, post);
     }
 }
 
