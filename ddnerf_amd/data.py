@@ -6,7 +6,8 @@ the thin part the training / eval loops need):
     = 1.8 GB -- nothing on a 288 GB card), so a training iteration does no host->device copy of rays;
   * sources: `blender` (transforms_*.json + PNG through PIL, data_utils/load_blender.py:68-145) and `procedural`
     (no files: camera ring around a seeded "teacher" DDNeRF whose fine render is the target; used where no dataset
-    exists -- smoke tests, training-parity curves).  LLFF / COLMAP loaders are not built (next tier)."""
+    exists -- smoke tests, training-parity curves); `llff` / `real360` (poses_bounds.npy scenes) in llff.py.  Running
+    COLMAP itself (data_utils/poses/) is out of scope: the scene must already carry poses_bounds.npy."""
 from __future__ import annotations
 
 import json
@@ -165,9 +166,17 @@ def get_datasets(cfg, device="cuda"):
         a = imgs[..., -1:]
         images = imgs[..., :3] * a + (1.0 - a) if cfg.nerf.train.white_background else imgs[..., :3] * a  # :37-41
         images, poses = torch.from_numpy(images), torch.from_numpy(poses)
-    elif kind in ("llff", "real360"):
-        raise NotImplementedError("LLFF / COLMAP loaders (data_utils/load_llff.py) are not part of this build yet; "
-                                  "use dataset.type blender or procedural")
+    elif kind in ("llff", "real360"):  # data_utils/data_utils.py:43-63
+        from .llff import load_llff
+
+        imgs, poses5, _bds, render_poses, i_test = load_llff(cfg)
+        H, W, focal = (float(v) for v in poses5[0, :3, -1])
+        H, W = int(H), int(W)
+        n_img = imgs.shape[0]
+        i_val = np.arange(n_img)[:: cfg.dataset.llffhold] if cfg.dataset.llffhold > 0 else np.array([i_test])
+        i_train = np.array([i for i in range(n_img) if i not in i_val])
+        images, poses = torch.from_numpy(imgs), torch.from_numpy(np.ascontiguousarray(poses5[:, :3, :4]))
+        render_poses = torch.from_numpy(np.ascontiguousarray(render_poses[:, :3, :4]).astype(np.float32))
     else:
         raise SystemExit("unknown dataset type %r" % cfg.dataset.type)  # data_utils/data_utils.py:15-16
     if cfg.dataset.normalize_poses:  # data_utils/data_utils.py:65-74: the model reads the rescaled near/far live
