@@ -8,7 +8,8 @@ in render mode; train mode adds the RCCL gradient all-reduce).  Inputs are resid
 
 Prints ONE JSON line on rank 0 with the metric, a `roofline` object for the dominant kernel (the fused fine-MLP
 forward: algorithmic FLOP per launch / mean launch duration measured with HIP events on the launch stream) and,
-at N=1, a `cpu_baseline` object (the CPU oracle timed on a bounded sample of the same workload).
+at N=1, a `cpu_baseline` object (the CPU oracle timed on a bounded sample of the same workload) and a `bf16_tier`
+object (the same workload on the bf16-MFMA MLP kernel, with its own roofline fraction against the bf16 MFMA peak).
 """
 import argparse
 import json
@@ -39,11 +40,12 @@ def parse():
     p.add_argument("--mode", choices=["render", "train"], default="render")
     p.add_argument("--mlp", choices=["fp32", "bf16"], default="fp32")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-bf16-tier", action="store_true", help="skip the extra bf16-MFMA measurement of the default run")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays of the same workload timed on the CPU oracle")
     return p.parse_args()
 
 
-def build_model(args, device):
+def build_model(args, device, mlp=None):
     from ddnerf_amd import synthetic
     from ddnerf_amd.cfgnode import CfgNode
     from models import models
@@ -52,7 +54,7 @@ def build_model(args, device):
     for mode in ("train", "validation"):
         cfg.nerf[mode]["num_coarse"] = args.coarse
         cfg.nerf[mode]["num_fine"] = args.fine
-    cfg.nerf["mlp_dtype"] = args.mlp
+    cfg.nerf["mlp_dtype"] = mlp or args.mlp
     cfg.train_params.dist_reg_coeficient = min(max(1 / args.coarse, 0.01), 0.12)  # train_model.py:124-125
     model = getattr(models, cfg.nerf.type)(cfg)
     sd_c = synthetic.make_state_dict(True, 11, 20.0)   # weight set B ("sharpened"), SURVEY.md 8d
@@ -83,6 +85,41 @@ class KernelTimer:
     def mean_ms(self, M):
         ts = [a.elapsed_time(b) for m, a, b in self.pairs if m == M]
         return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
+
+
+def bf16_tier(args, device, ro, rd, rad, tgt):
+    """The same render workload on the bf16-MFMA MLP kernel (BASELINE configs[2]'s numerical mode; the north-star
+    roofline target is stated against the bf16 MFMA peak).  Reported beside the fp32 headline, never as `value`."""
+    from ddnerf_amd import ops
+
+    model, _, _, _ = build_model(args, device, mlp="bf16")
+    model.eval()
+    timer = KernelTimer()
+    ops.MLP_LAUNCH_HOOK = timer
+
+    def step():
+        with torch.no_grad():
+            return model.run_iter(ro, rd, rad, mode="validation", rgb_target=tgt)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timer.active = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.active = False
+    ops.MLP_LAUNCH_HOOK = None
+    M_fine = args.rays * args.fine
+    ms, launches = timer.mean_ms(M_fine)
+    ach = M_fine * FLOP_FINE / (ms * 1e-3) / 1e12
+    return {"value": round(args.rays * args.steps / dt, 1), "unit": "rays/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "dtype": "bf16 (f32 accumulate)",
+            "roofline": {"bound": "mfma", "kernel": "mlp_bf16_fwd_kernel<fine> (%d samples/launch)" % M_fine,
+                         "achieved": round(ach, 2), "peak": PEAK["bf16"], "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK["bf16"], 4), "launch_ms": round(ms, 4), "launches_timed": launches}}
 
 
 def cpu_baseline(args, cfg, sd_c, sd_f):
@@ -199,6 +236,8 @@ def main():
                        "parallelism": "dp%d (independent ray batches)" % world},
             "roofline": roof,
         }
+        if world == 1 and args.mode == "render" and args.mlp == "fp32" and not args.no_bf16_tier:
+            line["bf16_tier"] = bf16_tier(args, device, ro, rd, rad, tgt)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f)
         print(json.dumps(line), flush=True)
