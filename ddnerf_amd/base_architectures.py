@@ -67,6 +67,17 @@ class _FusedMLP(torch.nn.Module):
             self._flatten()
         return self._flat
 
+    def param_version(self) -> int:
+        """changes whenever any parameter is written in place (Adam step, load_state_dict, manual edits)"""
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters())
+        return sum(p._version for p in plist)
+
+    def invalidate_packed(self):
+        """drop the kernel-format weight images (call after writing the flat buffer directly, e.g. a broadcast)"""
+        self.__dict__.pop("_packed_cache", None)
+
     def forward(self, x):
         """x: [M,123] (`embedded`, models/models.py:133) or the 128-column padded feature rows -> [M,4|6]"""
         if x.shape[-1] == 123:

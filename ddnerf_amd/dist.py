@@ -79,3 +79,4 @@ def broadcast_parameters(nets, src=0, group=None):
             continue
         seen.add(id(n))
         td.broadcast(n.flat_params(), src=src, group=group)
+        n.invalidate_packed()  # the flat buffer was written behind the parameters' version counters

@@ -14,12 +14,13 @@ from . import ops
 
 # ---- MLP -------------------------------------------------------------------------------------------------
 def _cached_pack(net, kind, builder):
-    """kernel-format weights, repacked only when the flat parameter buffer changed (optimizer step, load_state_dict).
+    """kernel-format weights, repacked only when a parameter changed (optimizer step, load_state_dict).
     The cache lives ON the module: a global table keyed by id(net) would hand a new model the packed weights of a
-    garbage-collected one that happened to get the same id and buffer address."""
+    garbage-collected one that happened to get the same id and buffer address.  The parameters alias the flat buffer
+    through `.data`, so in-place updates bump THEIR version counters, not the buffer's: the tag sums those."""
     flat = net.flat_params()
     cache = net.__dict__.setdefault("_packed_cache", {})
-    tag = (flat.data_ptr(), flat._version)
+    tag = (flat.data_ptr(), net.param_version())
     hit = cache.get(kind)
     if hit is not None and hit[0] == tag:
         return hit[1]

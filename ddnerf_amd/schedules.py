@@ -13,10 +13,14 @@ def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr
     return delay_rate * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
-def lr_at(step, train_iters):
-    """the schedule train_model.py hard-wires (:101-107): 5e-4 -> 5e-6, 2500-step x0.01 warm-up; cfg.optimizer.lr is
-    ignored by the reference"""
-    return learning_rate_decay(step, 0.0005, 5e-6, train_iters, lr_delay_steps=2500, lr_delay_mult=0.01)
+def lr_at(step, train_iters, scheduler=None):
+    """the schedule train_model.py hard-wires (:101-107): 5e-4 -> 5e-6, 2500-step x0.01 warm-up; cfg.optimizer.lr and
+    the shipped cfg.scheduler keys are ignored by the reference.  Extension: optional `scheduler.lr_init / lr_final /
+    lr_delay_steps / lr_delay_mult` keys override the hard-wired values (short procedural runs would otherwise spend
+    their whole life inside the warm-up); absent keys keep the reference's numbers."""
+    get = (lambda k, d: scheduler.get(k, d)) if scheduler is not None and hasattr(scheduler, "get") else (lambda k, d: d)
+    return learning_rate_decay(step, get("lr_init", 0.0005), get("lr_final", 5e-6), train_iters,
+                               lr_delay_steps=get("lr_delay_steps", 2500), lr_delay_mult=get("lr_delay_mult", 0.01))
 
 
 def mse2psnr(mse):

@@ -29,7 +29,7 @@ class TrainStepper:
         cfg, model, i = self.cfg, self.model, self.iter
         self.smooth.apply(model.cfg, i)
         model.train()
-        lr = schedules.lr_at(i, cfg.experiment.train_iters)
+        lr = schedules.lr_at(i, cfg.experiment.train_iters, cfg.get("scheduler", None) if hasattr(cfg, "get") else None)
         for o in self.optims:
             for gp in o.param_groups:
                 gp["lr"] = lr

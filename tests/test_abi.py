@@ -79,3 +79,32 @@ def test_model_surface_and_checkpoint_keys():
     for name in ("run_iter", "to", "train", "eval", "load_weights_from_checkpoint", "predict", "run_network",
                  "get_rays_batches"):
         assert callable(getattr(m, name))
+
+
+def test_packed_weight_cache_follows_parameter_updates():
+    """Regression: the parameters alias the flat buffer through `.data`, so an optimizer step bumps THEIR version
+    counters and not the buffer's -- the kernel-format weight cache must be keyed on the former, or training would
+    keep evaluating the initial weights."""
+    import torch
+    from ddnerf_amd import base_architectures as ba, functions as F
+
+    net = ba.MipNeRFModel(include_input_dir=True)
+    calls = []
+
+    def builder(flat, depth_head):
+        calls.append(float(flat.sum()))
+        return len(calls)
+
+    assert F._cached_pack(net, "x", builder) == 1 and F._cached_pack(net, "x", builder) == 1
+    opt = torch.optim.Adam(net.parameters(), lr=0.1)
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert F._cached_pack(net, "x", builder) == 2 and calls[1] != calls[0]      # repacked from the updated buffer
+    sd = {k: torch.zeros_like(v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    assert F._cached_pack(net, "x", builder) == 3 and calls[2] == 0.0
+    with torch.no_grad():
+        net.flat_params().add_(1.0)          # direct write (what a broadcast does) needs the explicit invalidation
+    net.invalidate_packed()
+    assert F._cached_pack(net, "x", builder) == 4 and calls[3] == float(net.flat_params().numel())

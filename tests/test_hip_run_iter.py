@@ -105,6 +105,30 @@ def test_run_iter_forward_matches_reference(name):
         assert set(out[0].keys()) == {"rgb", "disp", "acc", "weights", "depth"}
 
 
+@pytest.mark.parametrize("name", ["runiter_dd_blender_64x128_validation", "runiter_dd_llff_16x16_validation", "runiter_mip_blender_64x128_validation"])
+def test_run_iter_bf16_tier(name):
+    """The bf16-MFMA MLP is its own tolerance tier ('expect ~1e-2 / >= 40 dB; a tolerance tier to be
+    fixed empirically'): same rays / weights as the fp32 fixtures, RGB PSNR against the reference's fp32 output."""
+    if name not in runiter_names():
+        pytest.skip("fixture not generated")
+    c = load_runiter(name)
+    g = c["g"]
+    model = build_model(c)
+    model.cfg.nerf["mlp_dtype"] = "bf16"
+    model._set_mlp_dtype()
+    model.eval()
+    d = lambda x: torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        out = model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode=c["mode"], rgb_target=d(g["tgt"]))
+    for lvl in (0, 1):
+        rgb, ref = out[lvl]["rgb"].cpu().numpy(), g["o%d_rgb" % lvl]
+        psnr = -10.0 * np.log10(max(float(np.mean((rgb - ref) ** 2)), 1e-20))
+        assert psnr >= 40.0, (lvl, psnr)
+        assert np.abs(rgb - ref).max() <= 3e-2, (lvl, np.abs(rgb - ref).max())
+        depth, dref = out[lvl]["depth"].cpu().numpy(), g["o%d_depth" % lvl]
+        assert np.abs(depth - dref).max() <= 5e-2 * max(1.0, np.abs(dref).max()), lvl
+
+
 def test_validation_reshape_and_chunking():
     """image-shaped validation input, ray chunks smaller than the image: outputs are reshaped / concatenated
     like models/models.py:53-72, and equal the unchunked result."""

@@ -78,7 +78,7 @@ def main():
             vals = [float(x) for x in parts]
             psnr_fine = schedules.mse2psnr(vals[1])
             rec = {"iter": i, "loss": float(loss), "psnr_coarse": schedules.mse2psnr(vals[0]), "psnr_fine": psnr_fine,
-                   "lr": schedules.lr_at(i, cfg.experiment.train_iters), "s_per_iter":
+                   "lr": schedules.lr_at(i, cfg.experiment.train_iters, cfg.get("scheduler", None) if hasattr(cfg, "get") else None), "s_per_iter":
                    (time.time() - t_last) / max(1, cfg.experiment.print_every)}
             t_last = time.time()
             print(cfg.experiment.id + "\n[TRAIN] Iter: %d Loss: %s PSNR: %s dp coef: %s"
