@@ -397,6 +397,53 @@ def gen_runiter():
                  **flat_out(out), **rec, **rnd_named, **extra)
 
 
+def gen_trainsteps():
+    """A few whole optimiser steps of the reference's loop (train_model.py:144-177: run_iter, loss assembly, backward,
+    one Adam per network) on fixed rays with replayed randoms: pins that every step evaluates the UPDATED weights."""
+    n, nc, nf, steps, lr = 32, 32, 32, 5, 1e-3
+    for model_type, kind in (("DDNerfModel", "blender"), ("GeneralMipNerfModel", "blender")):
+        dd = model_type == "DDNerfModel"
+        cfg = load_cfg((CFG_OF if dd else CFG_MIP_OF)[kind], nc, nf, kind)
+        cfg.nerf.train["radiance_field_noise_std"] = 1.0
+        if cfg.train_params.set_automatic_dist_reg_coeficient:
+            cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+        model = getattr(ref_models, cfg.nerf.type)(cfg)
+        load_weights(model.coarse, dd, 11, 4.0)
+        if dd:
+            load_weights(model.fine, False, 12, 4.0)
+        optims = [torch.optim.Adam(model.coarse.parameters(), lr=lr)]
+        if dd:
+            optims.append(torch.optim.Adam(model.fine.parameters(), lr=lr))
+        ro, rd, rad, tgt = synthetic.make_rays(kind, n, seed=8)
+        shapes = [("rand", (n, nc + 1)), ("randn", (n, nc)), ("rand", (n, nf + 1)), ("randn", (n, nf))]
+        model.train()
+        rec = {}
+        for it in range(steps):
+            rnd = replay_randoms(100 + it, shapes)
+            torch.manual_seed(100 + it)
+            out = model.run_iter(T(ro), T(rd), T(rad), mode="train", rgb_target=T(tgt))
+            mses = [torch.nn.functional.mse_loss(out[j]["rgb"], T(tgt)) for j in range(len(out))]
+            loss = sum(cfg.train_params.loss_coeficients[j] * mses[j] for j in range(len(out)))
+            if dd:
+                loss = loss + cfg.train_params.dp_coeficient * out[1]["dp_loss"].mean()
+            loss.backward()
+            for o in optims:
+                o.step()
+                o.zero_grad()
+            rec["loss%d" % it] = loss.detach()
+            rec["mse%d" % it] = torch.stack([m.detach() for m in mses])
+            for i, r in enumerate(rnd):
+                rec["rnd%d_%d" % (it, i)] = r
+        nets = [("c", model.coarse)] + ([("f", model.fine)] if dd else [])
+        for pfx, net in nets:
+            for name, p in net.named_parameters():
+                rec["p%s_%s_sub" % (pfx, name)] = p.detach().reshape(-1)[::61].clone()
+        save("trainsteps_%s_%s" % ("dd" if dd else "mip", kind), ro=ro, rd=rd, rad=rad, tgt=tgt,
+             meta=np.array([nc, nf, 4.0, 1.0, float(cfg.dataset.near), float(cfg.dataset.far),
+                            float(cfg.train_params.dist_reg_coeficient), float(cfg.train_params.gaussian_smooth_factor),
+                            int(cfg.train_params.pdf_padding), steps, lr]), **rec)
+
+
 def gen_dploss():
     """estimate_dp_loss in isolation, incl. the row-filter misalignment and the all-filtered return."""
     rng = np.random.Generator(np.random.PCG64(55))
@@ -464,6 +511,6 @@ def gen_raygen():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen"]
+    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps"]
     for w in which:
         globals()["gen_" + w]()

@@ -213,3 +213,48 @@ def test_forward_sees_optimizer_updates(ops):
     ref.square().mean().backward()
     g_ref = sd["fc_feat.weight"].grad
     assert (g_fused - g_ref).norm() <= 2e-3 * g_ref.norm()
+
+
+@pytest.mark.parametrize("name", ["trainsteps_dd_blender", "trainsteps_mip_blender"])
+def test_training_steps_follow_reference(name):
+    """Five whole optimiser steps (run_iter, loss, backward, Adam per network -- train_model.py:144-177) through
+    `TrainStepper` against the reference's loss trajectory and final parameters on the same rays / random draws."""
+    import os
+    from _cases import GOLDEN
+    from ddnerf_amd import synthetic, train_step
+    from test_hip_run_iter import ReplayRng, build_model
+
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    nc, nf, sharpen, noise, near, far, dist_reg, smooth, pad, steps, lr = (float(v) for v in g["meta"])
+    dd = "_dd_" in name
+    c = dict(g={"rnd0": g["rnd0_1"], "rnd1": g["rnd0_3"]}, dd=dd, kind="blender", nc=int(nc), nf=int(nf), noise=noise, near=near, far=far, dist_reg=dist_reg,
+             smooth=smooth, pdf_padding=bool(pad), train=False,
+             sd_coarse=synthetic.make_state_dict(dd, 11, sharpen), sd_fine=synthetic.make_state_dict(False, 12, sharpen) if dd else None)
+    model = build_model(c)
+    cfg = model.cfg
+    cfg.train_params.set_automatic_dist_reg_coeficient = False
+    cfg.train_params.final_smooth = cfg.train_params.gaussian_smooth_factor      # the fixture keeps the smoothing constant
+    cfg["scheduler"] = {"lr_init": lr, "lr_final": lr, "lr_delay_steps": 0}      # ... and the learning rate
+    draws = []
+    for it in range(int(steps)):
+        for i, kind in enumerate(("rand", "randn", "rand", "randn")):
+            draws.append((kind, g["rnd%d_%d" % (it, i)]))
+    model.rng = ReplayRng(draws)
+    stepper = train_step.TrainStepper(model, cfg)
+    d = lambda x: torch.from_numpy(x).cuda()
+    ro, rd, rad, tgt = d(g["ro"]), d(g["rd"]), d(g["rad"]), d(g["tgt"])
+    for it in range(int(steps)):
+        loss, parts, _ = stepper.step(ro, rd, rad, tgt)
+        ref = float(g["loss%d" % it])
+        assert abs(float(loss) - ref) <= 2e-4 * max(1.0, abs(ref)), (it, float(loss), ref)
+        mse = g["mse%d" % it]
+        assert np.allclose([float(p) for p in parts[:2]], mse, rtol=2e-3, atol=1e-6), (it, parts, mse)
+    assert float(g["loss4"]) < 0.9 * float(g["loss0"])          # the trajectory really moves
+    nets = [("c", model.coarse)] + ([("f", model.fine)] if dd else [])
+    for pfx, net in nets:
+        for pname, p in net.named_parameters():
+            ref = torch.from_numpy(g["p%s_%s_sub" % (pfx, pname)])
+            mine = p.detach().reshape(-1)[::61].cpu()
+            # Adam normalises the step: parameters moved by ~steps*lr each; agreement to a small fraction of that
+            assert float((mine - ref).abs().max()) <= 0.25 * steps * lr, (pfx, pname, float((mine - ref).abs().max()))
+            assert float((mine - ref).norm()) <= 0.05 * float(steps * lr * np.sqrt(ref.numel())) + 1e-7, (pfx, pname)
