@@ -42,6 +42,8 @@ _SIGS = {
     "ddnerf_mlp_f32_wgrad_workspace_floats": (C.c_size_t, [C.c_long]),
     "ddnerf_mlp_f32_wgrad": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
                                        C.c_int, C.c_int, c_fp, c_fp, c_fp]),
+    "ddnerf_mlp_x3_wgrad": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
+                                       C.c_int, C.c_int, c_fp, c_fp, c_fp]),
 }
 
 _lib = None

@@ -8,6 +8,7 @@
 // a second kernel adds the slabs in a fixed order (split-K without atomics: training stays reproducible).
 // Bias gradients (row sums of delta) fall out of the A fragments on the VALU.
 #include "mlp_f32_common.h"
+#include "wgrad_reduce.h"
 
 #define WG_TILE 32           // samples per LDS tile
 #define WG_LDW (WG_TILE + 4)  // LDS row stride in floats: conflict-free ds_read_b128 of 4 samples x 32 rows
@@ -105,32 +106,6 @@ __global__ __launch_bounds__(THREADS) void wgrad_f32_kernel(const float *__restr
             if (h == 0) bias_slabs[((size_t)blockIdx.x * nsub + sub) * n_out_pad + (rg * ROWT + rt) * 32 + i] = s;
         }
     }
-}
-
-// dst[r*dst_ld + dst_col0 + c] = sum over slabs (ascending) of slab[(src_row0 + r)*slab_ld + src_col0 + c]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slabs, int nslabs, size_t slab_stride,
-                                                           int slab_ld, int src_row0, int src_col0, int n_rows, int n_cols,
-                                                           float *__restrict__ dst, int dst_ld, int dst_col0) {
-    // 64 output elements per block; the slabs of an element are split over 4 thread groups (k mod 4), each keeping 4
-    // loads in flight; partial sums are combined in a fixed order (reproducible, no atomics)
-    __shared__ float part[4][64];
-    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + e;
-    const bool live = idx < n_rows * n_cols;
-    const int r = live ? idx / n_cols : 0, c = live ? idx % n_cols : 0;
-    const float *p = slabs + (size_t)(src_row0 + r) * slab_ld + src_col0 + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = g;
-    for (; k + 12 < nslabs; k += 16) {
-        s0 += p[(size_t)k * slab_stride];
-        s1 += p[(size_t)(k + 4) * slab_stride];
-        s2 += p[(size_t)(k + 8) * slab_stride];
-        s3 += p[(size_t)(k + 12) * slab_stride];
-    }
-    for (; k < nslabs; k += 4) s0 += p[(size_t)k * slab_stride];
-    part[g][e] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (g == 0 && live) dst[(size_t)r * dst_ld + dst_col0 + c] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
 DDN_EXPORT size_t ddnerf_mlp_f32_wgrad_workspace_floats(long M) {

@@ -4,6 +4,8 @@ Every function takes/returns torch tensors that live on the GPU, allocates outpu
 enqueues the kernel on torch's current stream.  No function has a CPU path."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -293,11 +295,16 @@ def ndc_rays(H, W, focal, origins, directions, near=1.0):
     return o, d, r
 
 
+# weight-gradient arithmetic: "x3" = bf16 matrix cores with exact hi/lo operand splits (3 MFMAs per product, ~2^-16
+# relative product error, HBM-bound); "f32" = the fp32 matrix cores (exact fp32 products, MFMA-bound, 3x slower)
+WGRAD_MODE = os.environ.get("DDNERF_WGRAD", "x3")
+
+
 def mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, dst, dst_ld, dst_col0, dst_bias, workspace):
     """dst[r*dst_ld + dst_col0 + c] = sum_s deltas[drow0+r][s] * acts[arow0+c][s]; dst_bias[r] = sum_s deltas[drow0+r][s]"""
-    _lib.check(_lib.lib().ddnerf_mlp_f32_wgrad(_ptr(deltas), drow0, n_out, _ptr(acts), arow0, n_in, n_in_used, M,
-                                               deltas.shape[1], _ptr(dst), dst_ld, dst_col0, _ptr(dst_bias),
-                                               _ptr(workspace), _stream()), "ddnerf_mlp_f32_wgrad")
+    fn = _lib.lib().ddnerf_mlp_x3_wgrad if WGRAD_MODE == "x3" else _lib.lib().ddnerf_mlp_f32_wgrad
+    _lib.check(fn(_ptr(deltas), drow0, n_out, _ptr(acts), arow0, n_in, n_in_used, M, deltas.shape[1], _ptr(dst), dst_ld,
+                  dst_col0, _ptr(dst_bias), _ptr(workspace), _stream()), "ddnerf_mlp_%s_wgrad" % WGRAD_MODE)
 
 
 def mlp_f32_weight_grads(net, acts, deltas, M):

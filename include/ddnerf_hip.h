@@ -183,6 +183,11 @@ size_t ddnerf_mlp_f32_wgrad_workspace_floats(long M);
 int ddnerf_mlp_f32_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,
                          long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
                          ddnerf_stream_t stream);
+/* Same contract on the bf16 matrix cores with every fp32 operand split exactly into hi + lo bf16 (three MFMAs per
+ * product, fp32 accumulation): relative product error ~2^-16, HBM-bound instead of MFMA-bound. */
+int ddnerf_mlp_x3_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,
+                         long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
+                         ddnerf_stream_t stream);
 
 #ifdef __cplusplus
 }
