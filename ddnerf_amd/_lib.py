@@ -22,6 +22,9 @@ _SIGS = {
     "ddnerf_mlp_bf16_packed_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_bf16_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_bf16_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
+    "ddnerf_mlp_x3_packed_bytes": (C.c_size_t, [C.c_int]),
+    "ddnerf_mlp_x3_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
+    "ddnerf_mlp_x3_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
     "ddnerf_dd_head_workspace_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddnerf_dd_head": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_float, C.c_float] + [c_fp] * 9 + [c_fp]),
     "ddnerf_composite_forward": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int] + [c_fp] * 7 + [c_fp]),

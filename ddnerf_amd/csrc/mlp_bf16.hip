@@ -21,15 +21,7 @@
 // piece per wave at a time, spread over the MFMA stream (LDS-DMA would need no VGPRs, but one global_load_lds costs
 // its wave 60-180 issue cycles, and -- issued through the builtin -- makes hipcc turn every counted lgkmcnt(N) of the
 // loop into lgkmcnt(0)); two stage buffers, one barrier per stage.
-#include <utility>
-
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
+#include "mlp_bf16_common.h"
 
 // ---- schedule -------------------------------------------------------------------------------------------
 // 11 packed layers as in the fp32 kernel: K (in) / NB (32-row out blocks):
@@ -104,11 +96,6 @@ __device__ __forceinline__ float srcb(const float *__restrict__ P, const PlanB &
     return 0.0f;
 }
 
-// k-order: inside every 16 columns the quads are stored [0,2,1,3]
-__host__ __device__ __forceinline__ constexpr int korder(int p) {  // packed position -> original column (an involution)
-    return (p & ~15) | ((p & 3) + 4 * (((p >> 2) & 1) * 2 + ((p >> 3) & 1)));
-}
-
 __global__ void mlp_bf16_pack_kernel(const float *__restrict__ P, PlanB pl, unsigned short *__restrict__ packed) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 16-bit word of the packed buffer
     if (idx >= pl.total_bytes / 2) return;
@@ -162,28 +149,6 @@ DDN_EXPORT int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *p
 #define NCOL 2                       // 32-sample column blocks per wave
 #define WG_SAMPLES (WG_WAVES * NCOL * 32)
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// LDS-DMA of the very first stage only (nothing to overlap it with); asm so that hipcc's wait-count pass does not see a
-// pending LDS write (it would degrade every later counted lgkmcnt(N) to lgkmcnt(0)).
-__device__ __forceinline__ void dma_piece(const char *__restrict__ gsrc_lane, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc_lane), "s"(lds_addr)
-                 : "memory");
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ unsigned lds_addr_of(const char *p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
-}
 __device__ __forceinline__ void dma_stage(const char *__restrict__ src, char *dst, int bytes, int wave, int lane) {
     const unsigned base = lds_addr_of(dst);
     for (int off = wave * 1024; off < bytes; off += WG_WAVES * 1024) dma_piece(src + off + lane * 16, base + off);
@@ -202,17 +167,6 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b, bool relu) {
         r = __builtin_bit_cast(bf16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, r), z));
     }
     return __builtin_bit_cast(unsigned, r);
-}
-
-// One of the two B files (HA; this layer's / the next layer's activations ping-pong between HA and HB, 128
-// registers each) is homed in the accumulator half of the unified register file: MFMA reads its B operand from there directly, and the arch VGPRs stay free
-// for the accumulator tiles, the A ring and the VALU temporaries.  Left to itself hipcc keeps shuttling them
-// (5,600 v_accvgpr moves and 109 spills measured); defining every packed word through this one-instruction asm
-// gives it the AGPR register class from birth.
-__device__ __forceinline__ unsigned to_agpr(unsigned v) {
-    unsigned a;
-    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
-    return a;
 }
 
 // B-operand source of k-step ks of a layer: KIND 0 first layer (xyz, X[0..5]); 1 hidden (H[ks]); 2 skip layer
@@ -293,14 +247,8 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
             acc[b & 1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % DEPTH], bsrc<KIND, ks>(H[c], X[c]),
                                                                     acc[b & 1][c], 0, 0, 0);
         if constexpr (p + DEPTH < P) read_a(std::integral_constant<int, p + DEPTH>{});
-        if constexpr (b + 1 < NBLK && ks >= NKS - 5 && ks < NKS - 1)  // next block's bias, one piece per step
-            read_bias(std::integral_constant<int, b + 1>{}, std::integral_constant<int, ks - (NKS - 5)>{});
-        if constexpr (NP > 0 && p / DMA_EVERY < NP && p % DMA_EVERY == 0) {
-            // slot of piece i: first park piece i-2 (its load has had two periods, > 500 cycles, to land), then fetch i
-            constexpr int i = p / DMA_EVERY;
-            if constexpr (i >= BF16_PFD) st_piece(std::integral_constant<int, (i >= BF16_PFD ? i - BF16_PFD : 0)>{});
-            ld_piece(std::integral_constant<int, i>{});
-        }
+        // (the re-pack comes BEFORE the bias piece of the same step: blocks b-1 and b+1 share an accumulator buffer, and for
+        // K = 96 both walk its quarters in the same steps)
         if constexpr (b > 0) {  // re-pack the previous block's tiles: 4 quarters x NCOL units spread over this block
             static_for<4 * NCOL>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
@@ -308,6 +256,14 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
                     repack(std::integral_constant<int, b - 1>{}, std::integral_constant<int, u % NCOL>{},
                            std::integral_constant<int, u / NCOL>{});
             });
+        }
+        if constexpr (b + 1 < NBLK && ks >= NKS - 5 && ks < NKS - 1)  // next block's bias, one piece per step
+            read_bias(std::integral_constant<int, b + 1>{}, std::integral_constant<int, ks - (NKS - 5)>{});
+        if constexpr (NP > 0 && p / DMA_EVERY < NP && p % DMA_EVERY == 0) {
+            // slot of piece i: first park piece i-2 (its load has had two periods, > 500 cycles, to land), then fetch i
+            constexpr int i = p / DMA_EVERY;
+            if constexpr (i >= BF16_PFD) st_piece(std::integral_constant<int, (i >= BF16_PFD ? i - BF16_PFD : 0)>{});
+            ld_piece(std::integral_constant<int, i>{});
         }
         __builtin_amdgcn_sched_barrier(0);
     });

@@ -29,23 +29,22 @@ def _cached_pack(net, kind, builder):
     return packed
 
 
+_PACK = {"fp32": ops.mlp_f32_pack, "x3": ops.mlp_x3_pack, "bf16": ops.mlp_bf16_pack}
+_FORWARD = {"fp32": ops.mlp_f32_forward, "x3": ops.mlp_x3_forward, "bf16": ops.mlp_bf16_forward}
+
+
 def _packed_weights(net):
-    if net.mlp_dtype == "fp32":
-        return _cached_pack(net, "fp32", ops.mlp_f32_pack)
-    return _cached_pack(net, "bf16", ops.mlp_bf16_pack)
+    return _cached_pack(net, net.mlp_dtype, _PACK[net.mlp_dtype])
 
 
 def _forward_kernel(feat, net):
-    packed = _packed_weights(net)
-    if net.mlp_dtype == "fp32":
-        return ops.mlp_f32_forward(feat, packed, net.depth_head)
-    return ops.mlp_bf16_forward(feat, packed, net.depth_head)
+    return _FORWARD[net.mlp_dtype](feat, _packed_weights(net), net.depth_head)
 
 
 class _MLPFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, net, *params):
-        if net.mlp_dtype != "fp32":
+        if net.mlp_dtype == "bf16":
             raise NotImplementedError("training runs on the fp32 MLP kernels; the bf16 kernel is inference-only so far")
         packed = _packed_weights(net)
         raw, acts = ops.mlp_f32_forward_train(feat, packed, net.depth_head)

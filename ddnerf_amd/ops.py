@@ -118,6 +118,31 @@ def mlp_bf16_forward(feat, packed, depth_head):
     return raw
 
 
+def mlp_x3_pack(params_flat, depth_head):
+    params_flat = _f32c(params_flat, "params")
+    nbytes = _lib.lib().ddnerf_mlp_x3_packed_bytes(int(depth_head))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=params_flat.device)
+    _lib.check(_lib.lib().ddnerf_mlp_x3_pack(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()), "ddnerf_mlp_x3_pack")
+    return packed
+
+
+def mlp_x3_forward(feat, packed, depth_head):
+    """the MLP on the bf16 matrix cores with exact hi/lo operand splits (fp32-class accuracy): feat fp32 [M,128] -> raw"""
+    feat = _f32c(feat, "feat")
+    M = feat.shape[0]
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_mlp_x3_forward(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), M, _stream()),
+                   "ddnerf_mlp_x3_forward")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw
+
+
 K_ORDER = [(p & ~15) | ((p & 3) + 4 * (((p >> 2) & 1) * 2 + ((p >> 3) & 1))) for p in range(FEAT_LD)]
 
 

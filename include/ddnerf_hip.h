@@ -86,6 +86,15 @@ int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *packed, ddne
 int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M,
                             ddnerf_stream_t stream);
 
+/* K2 "x3": the same network on the bf16 matrix cores at fp32-class accuracy -- every fp32 weight and activation is split
+ * exactly into hi + lo bf16, three MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulation: outputs within ~1e-6
+ * of an fp64 evaluation (exact-fp32 kernel 6e-8, plain bf16 6e-4).  feat is the fp32 [M,128] feature matrix in natural
+ * column order (as for ddnerf_mlp_f32_forward); replaces the same reference functions. */
+size_t ddnerf_mlp_x3_packed_bytes(int depth_head);
+int ddnerf_mlp_x3_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head, float *raw, long M,
+                          ddnerf_stream_t stream);
+
 /* a8  DD head, inline in DDNerfModel.predict  models/models.py:242-260, 266-273
  * raw6 [n,nc,6] -> mus, sigmas, left_tail, part_inside (raw sigma) and smoothed sigma/left/part, all [n,nc];
  * scal[4] = {mus_loss, sig_loss, mus_reg, sig_reg}.  workspace: ddnerf_dd_head_workspace_floats() floats. */

@@ -26,6 +26,10 @@ if which in ("both", "bf16"):
     p = ops.mlp_bf16_pack(flat, False)
     t = timeit(lambda: ops.mlp_bf16_forward(fb, p, False), 30)
     print("bf16 fwd  %.4f ms  %.1f TFLOP/s  frac %.4f" % (t, FL / t / 1e9, FL / t / 1e9 / 2500))
+if which in ("both", "x3"):
+    p = ops.mlp_x3_pack(flat, False)
+    t = timeit(lambda: ops.mlp_x3_forward(feat, p, False), 20)
+    print("x3   fwd  %.4f ms  %.1f TFLOP/s (fp32-equivalent)  x%.2f the fp32 MFMA peak; bf16 MFMA work %.1f TFLOP/s = frac %.4f" % (t, FL / t / 1e9, FL / t / 1e9 / 157.3, 3 * FL / t / 1e9, 3 * FL / t / 1e9 / 2500))
 if which in ("train",):
     p = ops.mlp_f32_pack(flat, False); pt = ops.mlp_f32_pack_t(flat, False)
     t = timeit(lambda: ops.mlp_f32_forward_train(feat, p, False), 5)

@@ -105,6 +105,25 @@ def test_run_iter_forward_matches_reference(name):
         assert set(out[0].keys()) == {"rgb", "disp", "acc", "weights", "depth"}
 
 
+@pytest.mark.parametrize("name", runiter_names())
+def test_run_iter_x3_meets_the_fp32_bar(name):
+    """`nerf.mlp_dtype: x3` (bf16 matrix cores, exact hi/lo operand splits) is held to the SAME bar as the exact fp32
+    kernel: RGB / depth / weights within 1e-4 of the reference on every fixture."""
+    c = load_runiter(name)
+    g = c["g"]
+    model = build_model(c)
+    model.cfg.nerf["mlp_dtype"] = "x3"
+    model._set_mlp_dtype()
+    d = lambda x: torch.from_numpy(x).cuda()
+    model.train() if c["train"] else model.eval()
+    with torch.no_grad():
+        out = model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode=c["mode"], rgb_target=d(g["tgt"]))
+    for lvl in (0, 1):
+        for k in ("rgb", "depth", "disp", "acc", "weights"):
+            e = relerr(out[lvl][k].cpu().numpy(), g["o%d_%s" % (lvl, k)])
+            assert e <= 1e-4, (lvl, k, e)
+
+
 @pytest.mark.parametrize("name", ["runiter_dd_blender_64x128_validation", "runiter_dd_llff_16x16_validation", "runiter_mip_blender_64x128_validation"])
 def test_run_iter_bf16_tier(name):
     """The bf16-MFMA MLP is its own tolerance tier ('expect ~1e-2 / >= 40 dB; a tolerance tier to be

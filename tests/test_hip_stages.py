@@ -79,6 +79,21 @@ def test_mlp_f32_ragged_and_large(ops):
         assert maxerr(raw, ref) <= 2e-6 * max(1.0, np.abs(ref).max()), (M, depth)
 
 
+def test_mlp_x3_fp32_class_accuracy(ops):
+    """The bf16x3 kernel (exact hi/lo operand splits, three MFMAs per product) against the oracle's fp32 evaluation:
+    ragged sizes, both heads, default and sharpened weights.  Bar: 2e-5 of the output scale -- 30x looser than the exact
+    fp32 kernel's bar, 50x tighter than what plain bf16 reaches, and far inside the 1e-4 RGB parity budget."""
+    rng = np.random.default_rng(5)
+    for M, depth, sharpen in ((1, True, 1.0), (127, False, 20.0), (129, True, 20.0), (1000, False, 1.0), (4097, True, 4.0)):
+        feat = np.zeros((M, 128), np.float32)
+        feat[:, :123] = rng.uniform(-1, 1, (M, 123)).astype(np.float32)
+        sd = synthetic.make_state_dict(depth, 3, sharpen)
+        packed = ops.mlp_x3_pack(dev(flat_params(sd, depth)), depth)
+        raw = host(ops.mlp_x3_forward(dev(feat), packed, depth))
+        ref = O.mlp_forward(feat, sd, depth)
+        assert maxerr(raw, ref) <= 2e-5 * max(1.0, np.abs(ref).max()), (M, depth, maxerr(raw, ref))
+
+
 def test_mlp_bf16_ragged_vs_bf16_emulation(ops):
     """bf16 kernel against an fp64 evaluation of the SAME bf16-rounded weights/features/activations:
     isolates kernel bugs (wrong k-permutation, tile maps) from the expected bf16 quantisation error."""
@@ -108,7 +123,8 @@ def test_mlp_bf16_ragged_vs_bf16_emulation(ops):
         fb = torch.from_numpy(np.ascontiguousarray(feat[:, ops.K_ORDER])).to(torch.bfloat16).cuda().contiguous()
         packed = ops.mlp_bf16_pack(dev(flat_params(sd, depth)), depth)
         raw = host(ops.mlp_bf16_forward(fb, packed, depth))
-        assert maxerr(raw, ref) <= 2e-3 * max(1.0, np.abs(ref).max()), (M, depth)   # rounding-boundary flips only
+        col_scale = np.maximum(np.abs(ref).max(0), 0.1)
+        assert (np.abs(raw - ref).max(0) <= 1.5e-3 * col_scale).all(), (M, depth, np.abs(raw - ref).max(0) / col_scale)   # rounding-boundary flips only
 
 
 @pytest.mark.parametrize("tag", ["lin", "disp", "ndc"])
