@@ -186,7 +186,6 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
                                               const char *__restrict__ dma_src, char *dma_dst) {
     constexpr int NKS = K / 16, P = NBLK * NKS, DEPTH = X3_DEPTH, ROWB = 2 * K + 16, SLB = slice_bytes(K);
     constexpr int PIECES = DMA_BYTES / 1024, NP = (PIECES + WG_WAVES - 1) / WG_WAVES;  // pieces of this wave
-    constexpr int DMA_EVERY = P / (NP > 0 ? NP : 1) > 0 ? P / (NP > 0 ? NP : 1) : 1;
     static_assert(NP <= P, "one staging slot per k-step at most");
     const char *a_lane = cur + (lane & 31) * ROWB + 16 * (lane >> 5);
     const char *b_lane = cur + 64 * ROWB + 16 * (lane >> 5);
@@ -207,32 +206,42 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
         acc[b & 1][4 * g + 2] = v.z;
         acc[b & 1][4 * g + 3] = v.w;
     };
+    const unsigned lane_off = wave * 1024 + lane * 16;  // uniform base + 32-bit lane offset: saddr-form global loads
     auto piece_ok = [&](int i) { return (i + 1) * WG_WAVES <= PIECES || wave + WG_WAVES * i < PIECES; };
     auto ld_piece = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if (piece_ok(i)) pf[i % X3_PFD] = *(const f32x4 *)(dma_src + (wave + WG_WAVES * i) * 1024 + lane * 16);
+#ifndef X3_NO_STAGE
+        if (piece_ok(i)) pf[i % X3_PFD] = *(const f32x4 *)(dma_src + i * (WG_WAVES * 1024) + lane_off);
+#endif
     };
     auto st_piece = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if (piece_ok(i)) *(f32x4 *)(dma_dst + (wave + WG_WAVES * i) * 1024 + lane * 16) = pf[i % X3_PFD];
+#ifndef X3_NO_STAGE
+        if (piece_ok(i)) *(f32x4 *)(dma_dst + i * (WG_WAVES * 1024) + lane_off) = pf[i % X3_PFD];
+#endif
     };
-    auto repack = [&](auto pbc, auto qc) {  // quarter q of the tile of block pb -> 2 packed hi pairs + 2 lo pairs
-        constexpr int pb = decltype(pbc)::value, q = decltype(qc)::value;
+    auto repack = [&](auto pbc, auto uc) {  // unit u (registers 2u, 2u+1) of the tile of block pb -> one hi pair + one lo pair
+        constexpr int pb = decltype(pbc)::value, u = decltype(uc)::value;
+#ifdef X3_NO_REPACK
+        if constexpr (u == 0) keep += acc[pb & 1];  // ablation: keeps the MFMAs alive without the hi/lo re-pack
+        if constexpr (false) {
+#else
         if constexpr (B0 + pb < NCONV) {
-            float x[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) x[c] = relu ? fmaxf(acc[pb & 1][4 * q + c], 0.0f) : acc[pb & 1][4 * q + c];
-            unsigned h0, l0, h1, l1;
-            split_pair(x[0], x[1], h0, l0);
-            split_pair(x[2], x[3], h1, l1);
-            u32x4 wh = __builtin_bit_cast(u32x4, Hnh[2 * (B0 + pb) + q / 2]);
-            u32x4 wl = __builtin_bit_cast(u32x4, Hnl[2 * (B0 + pb) + q / 2]);
-            wh[2 * (q & 1) + 0] = HN_AGPR ? to_agpr(h0) : h0;
-            wh[2 * (q & 1) + 1] = HN_AGPR ? to_agpr(h1) : h1;
-            wl[2 * (q & 1) + 0] = HN_AGPR ? to_agpr(l0) : l0;
-            wl[2 * (q & 1) + 1] = HN_AGPR ? to_agpr(l1) : l1;
-            Hnh[2 * (B0 + pb) + q / 2] = __builtin_bit_cast(bf16x8, wh);
-            Hnl[2 * (B0 + pb) + q / 2] = __builtin_bit_cast(bf16x8, wl);
+#endif
+            float x0 = acc[pb & 1][2 * u], x1 = acc[pb & 1][2 * u + 1];
+            if (relu) {  // on the bit patterns: one v_max_i32 each (fmaxf would add a canonicalising v_max per value)
+                x0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x0), 0));
+                x1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x1), 0));
+            }
+            unsigned hw, lw;
+            split_pair(x0, x1, hw, lw);
+            // registers 0..7 are k-step 2(B0+pb), 8..15 the next one; pair u&3 of that fragment
+            u32x4 wh = __builtin_bit_cast(u32x4, Hnh[2 * (B0 + pb) + u / 4]);
+            u32x4 wl = __builtin_bit_cast(u32x4, Hnl[2 * (B0 + pb) + u / 4]);
+            wh[u & 3] = HN_AGPR ? to_agpr(hw) : hw;
+            wl[u & 3] = HN_AGPR ? to_agpr(lw) : lw;
+            Hnh[2 * (B0 + pb) + u / 4] = __builtin_bit_cast(bf16x8, wh);
+            Hnl[2 * (B0 + pb) + u / 4] = __builtin_bit_cast(bf16x8, wl);
         }
     };
     static_for<4>([&](auto g) { read_bias(std::integral_constant<int, 0>{}, g); });
@@ -241,21 +250,32 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
     static_for<P>([&](auto pc) {
         constexpr int p = decltype(pc)::value, b = p / NKS, ks = p % NKS;
         const bf16x8 &bh = bsrc<KIND, ks>(Hh, Xh), &bl = bsrc<KIND, ks>(Hl, Xl);
+        // A 32x32x16 MFMA occupies the matrix pipe for 32 cycles but the wave's issue port for 4: everything else of the
+        // step is dealt into the three 28-cycle gaps (one sched_barrier per gap), never piled up behind the third MFMA.
+        constexpr int slot = NP > 0 ? (p * NP + P - 1) / P : 0;  // smallest i with (i * P) / NP >= p
+        constexpr bool dma_here = NP > 0 && slot < NP && (slot * P) / (NP > 0 ? NP : 1) == p;
+        // gap 1: this step's A-fragment prefetch + the park of the staging piece whose load has had PFD slots to land
         acc[b & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring_l[p % DEPTH], bh, acc[b & 1], 0, 0, 0);
+        if constexpr (dma_here && slot >= X3_PFD) st_piece(std::integral_constant<int, (slot >= X3_PFD ? slot - X3_PFD : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // gap 2: re-pack of the previous block's tile, its 8 register pairs spread over k-steps 1 .. NKS-2 -- always
+        // BEFORE the next block's bias piece: blocks b-1 and b+1 share an accumulator buffer, bias piece g (registers
+        // 4g..4g+3) lands in step NKS-5+g, pair u (registers 2u, 2u+1) is re-packed no later than that
         acc[b & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring_h[p % DEPTH], bl, acc[b & 1], 0, 0, 0);
+        if constexpr (b > 0) {
+            static_for<8>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                static_assert(1 + (u * (NKS - 2)) / 8 <= NKS - 5 + u / 2 || NBLK == 1, "re-pack after the bias overwrite");
+                if constexpr (1 + (u * (NKS - 2)) / 8 == ks) repack(std::integral_constant<int, (b > 0 ? b - 1 : 0)>{}, uc);
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // gap 3: the A fragments DEPTH steps ahead, the next block's bias piece, the fetch of staging piece `slot`
         acc[b & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring_h[p % DEPTH], bh, acc[b & 1], 0, 0, 0);
         if constexpr (p + DEPTH < P) read_a(std::integral_constant<int, p + DEPTH>{});
-        // re-pack the previous block's tile, one quarter per k-step -- BEFORE the next block's bias piece of the same step:
-        // blocks b-1 and b+1 share an accumulator buffer, and for K = 96 both walk its quarters in the same steps
-        if constexpr (b > 0 && ks >= 1 && ks <= 4)
-            repack(std::integral_constant<int, (b > 0 ? b - 1 : 0)>{}, std::integral_constant<int, (ks >= 1 && ks <= 4 ? ks - 1 : 0)>{});
-        if constexpr (b + 1 < NBLK && ks >= NKS - 5 && ks < NKS - 1)  // next block's bias, one piece per step
+        if constexpr (b + 1 < NBLK && ks >= NKS - 5 && ks < NKS - 1)
             read_bias(std::integral_constant<int, b + 1>{}, std::integral_constant<int, ks - (NKS - 5)>{});
-        if constexpr (NP > 0 && p / DMA_EVERY < NP && p % DMA_EVERY == 0) {
-            constexpr int i = p / DMA_EVERY;  // slot of piece i: park piece i - PFD (its load has had PFD periods), fetch i
-            if constexpr (i >= X3_PFD) st_piece(std::integral_constant<int, (i >= X3_PFD ? i - X3_PFD : 0)>{});
-            ld_piece(std::integral_constant<int, i>{});
-        }
+        if constexpr (dma_here) ld_piece(std::integral_constant<int, slot>{});
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<(NP < X3_PFD ? NP : X3_PFD)>([&](auto tc) {  // the pieces still in registers
@@ -263,8 +283,11 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
         st_piece(std::integral_constant<int, first_left + t>{});
     });
     constexpr int lb = NBLK - 1;  // the stage's last block is re-packed right away
-    static_for<4>([&](auto qc) { repack(std::integral_constant<int, lb>{}, qc); });
-    keep = acc[lb & 1];  // the layer's last tile (heads: rgb / mu,sigma rows; dir layer: alpha row)
+    static_for<8>([&](auto uc) { repack(std::integral_constant<int, lb>{}, uc); });
+#ifndef X3_NO_REPACK
+    keep = acc[lb & 1];  // the layer's last tile
+#endif
+    // the layer's last tile (heads: rgb / mu,sigma rows; dir layer: alpha row)
 }
 
 // One layer = its stages.  On entry the layer's first stage sits in LDS buffer PAR (parked by the previous stage).
@@ -281,7 +304,9 @@ __device__ __forceinline__ void layer(const char *__restrict__ &wp, char *lds, c
         char *cur = lds + ((PAR + st) & 1) * STAGE_BYTES_MAX;
         char *nxt = lds + ((PAR + st + 1) & 1) * STAGE_BYTES_MAX;
         dma_wait();       // (only the prologue's LDS-DMA of the very first stage is ever pending here)
+#ifndef X3_NO_BARRIER
         __syncthreads();  // every wave has parked its pieces of stage `st`; the other buffer is free again
+#endif
         wp += stage_bytes(L, st);
         constexpr int nbytes = st + 1 < NST ? stage_bytes(L, st + 1) : (NEXT >= 0 ? stage_bytes(NEXT >= 0 ? NEXT : 0, 0) : 0);
         stage_compute<KIND, K, nblk, first, NCONV, nbytes, HN_AGPR>(cur, Hh, Hl, Xh, Xl, Hnh, Hnl, keep, relu, lane, wave,
@@ -300,6 +325,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void mlp_x3_fwd_kernel(const float *
     const float *frow = feat + (size_t)(m < M ? m : M - 1) * DDNERF_FEAT_LD;
     bf16x8 HAh[16], HAl[16], HBh[16], HBl[16], Xh[8], Xl[8];
     f32x16 keep;
+#ifdef X3_NO_REPACK
+    for (int r = 0; r < 16; ++r) keep[r] = 0.f;
+#endif
     const char *wp = packed;
     dma_stage(wp, lds, stage_bytes(0, 0), wave, lane);
     // fp32 features, natural column order: position j of lane half h in k-step g is column 16g + 8(j>>2) + 4h + (j&3)
@@ -307,7 +335,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void mlp_x3_fwd_kernel(const float *
         constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
 #pragma unroll
         for (int g = g0; g < g1; ++g) {
+#ifdef X3_NT_FEAT
+            const f32x4 a = __builtin_nontemporal_load((const f32x4 *)(frow + 16 * g + 4 * h));
+            const f32x4 b = __builtin_nontemporal_load((const f32x4 *)(frow + 16 * g + 8 + 4 * h));
+#else
             const f32x4 a = *(const f32x4 *)(frow + 16 * g + 4 * h), b = *(const f32x4 *)(frow + 16 * g + 8 + 4 * h);
+#endif
             unsigned wh[4], wl[4];
             split_pair(a.x, a.y, wh[0], wl[0]);
             split_pair(a.z, a.w, wh[1], wl[1]);

@@ -24,6 +24,13 @@ for so in libs:
         assert L.ddnerf_mlp_bf16_pack(flat.data_ptr(), 0, packed.data_ptr(), st) == 0
         f = L.ddnerf_mlp_bf16_forward; f.argtypes = [V, V, C.c_int, V, C.c_long, V]
         runs.append((so, lambda f=f, packed=packed: f(fb.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)))
+    elif kind == "x3":
+        L.ddnerf_mlp_x3_packed_bytes.restype = C.c_size_t
+        packed = torch.empty(L.ddnerf_mlp_x3_packed_bytes(0), dtype=torch.uint8, device="cuda")
+        L.ddnerf_mlp_x3_pack.argtypes = [V, C.c_int, V, V]
+        assert L.ddnerf_mlp_x3_pack(flat.data_ptr(), 0, packed.data_ptr(), st) == 0
+        f = L.ddnerf_mlp_x3_forward; f.argtypes = [V, V, C.c_int, V, C.c_long, V]
+        runs.append((so, lambda f=f, packed=packed: f(feat.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)))
     else:
         L.ddnerf_mlp_f32_packed_floats.restype = C.c_size_t
         packed = torch.empty(L.ddnerf_mlp_f32_packed_floats(0), dtype=torch.float32, device="cuda")
@@ -38,7 +45,7 @@ for so, fn in runs:
 for o in outs[1:]:
     print("max |diff| vs first variant: %.3g" % float((o - outs[0]).abs().max()))
 times = {so: [] for so, _ in runs}
-reps = 20 if kind == "bf16" else 4
+reps = 20 if kind == "bf16" else (10 if kind == "x3" else 4)
 for _ in range(3):
     for so, fn in runs: fn()
 for rnd in range(12):
@@ -48,7 +55,7 @@ for rnd in range(12):
         for _ in range(reps): fn()
         e1.record(); torch.cuda.synchronize()
         times[so].append(e0.elapsed_time(e1) / reps)
-peak = 2500 if kind == "bf16" else 157.3
+peak = 2500 if kind == "bf16" else (2500 / 3 if kind == "x3" else 157.3)
 for so, ts in times.items():
     med = statistics.median(ts)
     print("%-40s median %.4f ms  min %.4f  frac(median) %.4f" % (os.path.basename(so), med, min(ts), 1220608 * M / med / 1e9 / peak))
