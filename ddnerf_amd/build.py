@@ -27,6 +27,7 @@ SOURCES = {
     # accumulators in arch VGPRs (the VALU re-pack reads them), B files in the accumulator half: see mlp_bf16.hip
     "mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "mlp_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+    "mlp_x3_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }
 
 
@@ -35,7 +36,7 @@ def _stale(target, deps):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_f32_common.h"), os.path.join(CSRC, "wgrad_reduce.h"), os.path.join(CSRC, "mlp_bf16_common.h"), os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_f32_common.h"), os.path.join(CSRC, "wgrad_reduce.h"), os.path.join(CSRC, "mlp_bf16_common.h"), os.path.join(CSRC, "mlp_x3_common.h"), os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)

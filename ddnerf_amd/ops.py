@@ -296,6 +296,43 @@ def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head):
     return deltas
 
 
+def mlp_x3_pack_t(params_flat, depth_head):
+    params_flat = _f32c(params_flat, "params")
+    packed = torch.empty(_lib.lib().ddnerf_mlp_x3_packed_t_bytes(int(depth_head)), dtype=torch.uint8, device=params_flat.device)
+    _lib.check(_lib.lib().ddnerf_mlp_x3_pack_t(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()), "ddnerf_mlp_x3_pack_t")
+    return packed
+
+
+def mlp_x3_forward_train(feat, packed, depth_head):
+    """x3 forward that records activations: -> raw [M,4|6], acts [2560, ld] fp32, bits [160, ld] uint16 (sign words)"""
+    feat = _f32c(feat, "feat")
+    M = feat.shape[0]
+    ld = (M + 127) // 128 * 128
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+    acts = torch.empty((ACT_ROWS, ld), dtype=torch.float32, device=feat.device)
+    bits = torch.empty((ACT_ROWS // 32 * 2, ld), dtype=torch.int16, device=feat.device)
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_mlp_x3_forward_train(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts),
+                                                          _ptr(bits), M, ld, _stream()), "ddnerf_mlp_x3_forward_train")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw, acts, bits
+
+
+def mlp_x3_backward_data(g_raw, packed_t, bits, depth_head):
+    g_raw = _f32c(g_raw, "g_raw")
+    M = g_raw.shape[0]
+    ld = bits.shape[1]
+    deltas = torch.empty((ACT_ROWS, ld), dtype=torch.float32, device=g_raw.device)
+    _lib.check(_lib.lib().ddnerf_mlp_x3_backward_data(_ptr(g_raw), _ptr(packed_t), _ptr(bits), int(depth_head), _ptr(deltas),
+                                                      M, ld, _stream()), "ddnerf_mlp_x3_backward_data")
+    return deltas
+
+
 # ---- ray generation (SURVEY.md 8f row 1) -------------------------------------------------------------------
 def ray_bundle(H, W, focal, cam2world, device="cuda"):
     """general_utils/nerf_helpers.py:67-125 -> origins [H,W,3], directions [H,W,3], radii [H,W,1]"""

@@ -95,6 +95,19 @@ int ddnerf_mlp_x3_pack(const float *params, int depth_head, void *packed, ddnerf
 int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head, float *raw, long M,
                           ddnerf_stream_t stream);
 
+/* x3 training kernels (same network, same accuracy class): the forward that records what the backward needs, the W^T
+ * images, and the fused backward-data pass -- drop-ins for ddnerf_mlp_f32_forward_train / _pack_t / _backward_data.
+ *   acts  [ddnerf_mlp_act_rows(), ld] fp32, [feature][sample] (row map as for the fp32 kernels); ld = M rounded up to 128
+ *   bits  [160, ld] uint16: word (tile*2 + lane_half) of a sample = signs of that lane's 16 values of 32-row tile `tile`
+ *         (relu' for the backward pass; 2 bytes instead of the 64-byte fp32 tile)
+ *   deltas [ddnerf_mlp_act_rows(), ld] fp32: every layer's pre-activation gradient, rows as in `acts`; rows 2432.. = d(raw) */
+int ddnerf_mlp_x3_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts, void *bits,
+                                long M, long ld, ddnerf_stream_t stream);
+size_t ddnerf_mlp_x3_packed_t_bytes(int depth_head);
+int ddnerf_mlp_x3_pack_t(const float *params, int depth_head, void *packed_t, ddnerf_stream_t stream);
+int ddnerf_mlp_x3_backward_data(const float *g_raw, const void *packed_t, const void *bits, int depth_head, float *deltas,
+                                long M, long ld, ddnerf_stream_t stream);
+
 /* a8  DD head, inline in DDNerfModel.predict  models/models.py:242-260, 266-273
  * raw6 [n,nc,6] -> mus, sigmas, left_tail, part_inside (raw sigma) and smoothed sigma/left/part, all [n,nc];
  * scal[4] = {mus_loss, sig_loss, mus_reg, sig_reg}.  workspace: ddnerf_dd_head_workspace_floats() floats. */
