@@ -42,16 +42,26 @@ __host__ __device__ constexpr int x3_layer_off(int l) {
     return off;
 }
 
+// byte offset of every layer's first stage, as a compile-time table (the pack kernels index it per thread)
+template <class PL>
+struct X3LayerOffsets {
+    int v[PL::NL + 1];
+    constexpr X3LayerOffsets() : v() {
+        for (int l = 0; l <= PL::NL; ++l) v[l] = x3_layer_off<PL>(l);
+    }
+};
+
 // Packs one 16-bit word of a plan's image: SRCW(l, out_row, in_col) / SRCB(l, out_row) supply the fp32 values.
 template <class PL, class SRCW, class SRCB>
 __device__ __forceinline__ unsigned short x3_pack_word(int idx, SRCW &&srcw, SRCB &&srcb) {
+    constexpr X3LayerOffsets<PL> offs{};
     int byte = idx * 2, l = PL::NL - 1;
-    while (l > 0 && byte < x3_layer_off<PL>(l)) --l;
-    int rel = byte - x3_layer_off<PL>(l), st = 0;
-    while (rel >= x3_stage_bytes<PL>(l, st)) {
-        rel -= x3_stage_bytes<PL>(l, st);
-        ++st;
-    }
+    while (l > 0 && byte < offs.v[l]) --l;
+    int rel = byte - offs.v[l], st = 0;
+    // all stages of a layer but the last have the same size
+    const int full = x3_round_kib(PL::SPS[l] * x3_slice_bytes(PL::K[l]));
+    st = rel / full;
+    rel -= st * full;
     const int K = PL::K[l], rowb = 2 * K + 16;
     const int sl = rel / x3_slice_bytes(K);
     const int first = st * PL::SPS[l];
