@@ -89,49 +89,28 @@ class KernelTimer:
         return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
 
 
-def extra_tier(args, device, ro, rd, rad, tgt, mlp):
+def extra_tier(args, mlp):
     """The same render workload on another MLP kernel, reported beside the exact-fp32 headline, never as `value`:
     "bf16" = plain bf16 MFMA (BASELINE configs[2]'s numerical mode; the north-star roofline target is stated against the
     bf16 MFMA peak); "x3" = bf16 MFMA with exact hi/lo operand splits (three MFMAs per product, fp32-class accuracy: it
-    meets the same 1e-4 parity bar as the exact kernel) -- its roofline counts the 3x bf16 MFMA work it really issues."""
-    import gc
+    meets the same 1e-4 parity bar as the exact kernel) -- its roofline counts the 3x bf16 MFMA work it really issues.
+    Measured by a child `bench.py --mlp <tier>` run so that it sees a fresh allocator / launch-path state (inside this
+    process, behind the fp32 run, the CPU-launch-bound bf16 step measures up to 4x slower)."""
+    import subprocess
 
-    from ddnerf_amd import ops
-
-    # start from the allocator state a stand-alone `--mlp <tier>` run would see: with the previous model's larger cached
-    # blocks in the pool the (CPU-launch-bound) bf16 step measures 25 % slower
-    gc.collect()
-    torch.cuda.empty_cache()
-    model, _, _, _ = build_model(args, device, mlp=mlp)
-    model.eval()
-    timer = KernelTimer()
-    ops.MLP_LAUNCH_HOOK = timer
-
-    def step():
-        with torch.no_grad():
-            return model.run_iter(ro, rd, rad, mode="validation", rgb_target=tgt)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    timer.active = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timer.active = False
-    ops.MLP_LAUNCH_HOOK = None
-    M_fine = args.rays * args.fine
-    ms, launches = timer.mean_ms(M_fine)
-    work = 3 if mlp == "x3" else 1
-    ach = work * M_fine * FLOP_FINE / (ms * 1e-3) / 1e12
-    return {"value": round(args.rays * args.steps / dt, 1), "unit": "rays/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "dtype": DTYPE[mlp],
-            "roofline": {"bound": "mfma", "kernel": "mlp_%s_fwd_kernel<fine> (%d samples/launch)" % (mlp, M_fine),
-                         "achieved": round(ach, 2), "peak": PEAK["bf16"], "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK["bf16"], 4), "launch_ms": round(ms, 4), "launches_timed": launches,
-                         "fp32_equivalent_tflops": round(M_fine * FLOP_FINE / (ms * 1e-3) / 1e12, 2)}}
+    cmd = [sys.executable, os.path.abspath(__file__), "--mlp", mlp, "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--rays", str(args.rays), "--coarse", str(args.coarse), "--fine", str(args.fine), "--no-cpu-baseline",
+           "--no-bf16-tier"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # the headline must not die with a tier
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    roof = d["roofline"]
+    if roof:
+        roof.pop("traffic", None)
+        roof["fp32_equivalent_tflops"] = round(roof["achieved"] / (3 if mlp == "x3" else 1), 2)
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "roofline": roof}
 
 
 def cpu_baseline(args, cfg, sd_c, sd_f):
@@ -249,9 +228,8 @@ def main():
             "roofline": roof,
         }
         if world == 1 and args.mode == "render" and args.mlp == "fp32" and not args.no_bf16_tier:
-            del model, step
-            line["x3_tier"] = extra_tier(args, device, ro, rd, rad, tgt, "x3")
-            line["bf16_tier"] = extra_tier(args, device, ro, rd, rad, tgt, "bf16")
+            line["x3_tier"] = extra_tier(args, "x3")
+            line["bf16_tier"] = extra_tier(args, "bf16")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f)
         print(json.dumps(line), flush=True)

@@ -247,16 +247,23 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
             acc[b & 1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % DEPTH], bsrc<KIND, ks>(H[c], X[c]),
                                                                     acc[b & 1][c], 0, 0, 0);
         if constexpr (p + DEPTH < P) read_a(std::integral_constant<int, p + DEPTH>{});
-        // (the re-pack comes BEFORE the bias piece of the same step: blocks b-1 and b+1 share an accumulator buffer, and for
-        // K = 96 both walk its quarters in the same steps)
-        if constexpr (b > 0) {  // re-pack the previous block's tiles: 4 quarters x NCOL units spread over this block
-            static_for<4 * NCOL>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                if constexpr (1 + (u * (NKS - 2)) / (4 * NCOL) == ks)
-                    repack(std::integral_constant<int, b - 1>{}, std::integral_constant<int, u % NCOL>{},
-                           std::integral_constant<int, u / NCOL>{});
-            });
-        }
+        // Blocks b-1 and b+1 share an accumulator buffer: the bias piece g of block b+1 (registers 4g..4g+3, step NKS-5+g)
+        // must not land before quarter g of block b-1 has been re-packed.  For K >= 160 the re-pack is always steps
+        // ahead and runs LAST in the step (its VALU work then overlaps the LDS / global latencies issued before it); for
+        // K = 96 both walk the quarters in the same steps, so there the re-pack comes first.
+        constexpr bool REPACK_FIRST = NKS < 10;
+        auto repack_step = [&]() {
+            if constexpr (b > 0) {  // re-pack the previous block's tiles: 4 quarters x NCOL units spread over this block
+                static_for<4 * NCOL>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    static_assert(REPACK_FIRST || 1 + (u * (NKS - 2)) / (4 * NCOL) < NKS - 5 + u / NCOL, "bias lands on a live quarter");
+                    if constexpr (1 + (u * (NKS - 2)) / (4 * NCOL) == ks)
+                        repack(std::integral_constant<int, (b > 0 ? b - 1 : 0)>{}, std::integral_constant<int, u % NCOL>{},
+                               std::integral_constant<int, u / NCOL>{});
+                });
+            }
+        };
+        if constexpr (REPACK_FIRST) repack_step();
         if constexpr (b + 1 < NBLK && ks >= NKS - 5 && ks < NKS - 1)  // next block's bias, one piece per step
             read_bias(std::integral_constant<int, b + 1>{}, std::integral_constant<int, ks - (NKS - 5)>{});
         if constexpr (NP > 0 && p / DMA_EVERY < NP && p % DMA_EVERY == 0) {
@@ -265,6 +272,7 @@ __device__ __forceinline__ void stage_compute(const char *__restrict__ cur, cons
             if constexpr (i >= BF16_PFD) st_piece(std::integral_constant<int, (i >= BF16_PFD ? i - BF16_PFD : 0)>{});
             ld_piece(std::integral_constant<int, i>{});
         }
+        if constexpr (!REPACK_FIRST) repack_step();
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<(NP < BF16_PFD ? NP : BF16_PFD)>([&](auto tc) {  // the pieces still in registers

@@ -1,0 +1,122 @@
+// Shared host/device helpers of libddnerf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ddnerf_hip.h"
+
+#define DDN_EXPORT extern "C" __attribute__((visibility("default")))
+
+static inline int ddn_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DDNERF_OK : (int)e;
+}
+
+#define DDN_REQUIRE(cond, code) \
+    do {                        \
+        if (!(cond)) return (code); \
+    } while (0)
+
+static inline bool ddn_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// ---- fp32 special functions, written with the reference's operation order -------------------------------
+
+// general_utils/math_utils.py:193-199   0.5*(1+erf(x/sqrt2)), sqrt2 = fp32
+__device__ __forceinline__ float ddn_norm_cdf(float x) {
+    const float sqrt2 = 1.41421354f;
+    return 0.5f * (1.0f + erff(x / sqrt2));
+}
+
+// torch.erfinv (ATen calc_erfinv<float>): rational start value + two Newton steps, float throughout.
+__device__ __forceinline__ float ddn_erfinv(float y) {
+    const float a0 = 0.886226899f, a1 = -1.645349621f, a2 = 0.914624893f, a3 = -0.140543331f;
+    const float b0 = -2.118377725f, b1 = 1.442710462f, b2 = -0.329097515f, b3 = 0.012229801f;
+    const float c0 = -1.970840454f, c1 = -1.624906493f, c2 = 3.429567803f, c3 = 1.641345311f;
+    const float d0 = 3.543889200f, d1 = 1.637067800f;
+    const float two_over_sqrtpi = 1.12837917f;  // 2.0f / float(sqrt(pi))
+    float ya = fabsf(y), x;
+    if (ya > 1.0f) return __builtin_nanf("");
+    if (ya == 1.0f) return copysignf(__builtin_inff(), y);
+    if (ya <= 0.7f) {
+        float z = y * y;
+        float num = (((a3 * z + a2) * z + a1) * z + a0);
+        float dem = ((((b3 * z + b2) * z + b1) * z + b0) * z + 1.0f);
+        x = y * num / dem;
+    } else {
+        float z = sqrtf(-logf((1.0f - ya) / 2.0f));
+        float num = ((c3 * z + c2) * z + c1) * z + c0;
+        float dem = (d1 * z + d0) * z + 1.0f;
+        x = copysignf(num, y) / dem;
+    }
+    x = x - (erff(x) - y) / (two_over_sqrtpi * expf(-x * x));
+    x = x - (erff(x) - y) / (two_over_sqrtpi * expf(-x * x));
+    return x;
+}
+
+// general_utils/math_utils.py:202-208
+__device__ __forceinline__ float ddn_norm_icdf(float x) {
+    const float sqrt2 = 1.41421354f;
+    return sqrt2 * ddn_erfinv(2.0f * x - 1.0f);
+}
+
+__device__ __forceinline__ float ddn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// torch.nn.functional.softplus(beta=1, threshold=20)
+__device__ __forceinline__ float ddn_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// torch.sum(x, dim=-1) on a contiguous fp32 row, ATen CPU order (8-lane vectors x 4 accumulators; rows
+// shorter than 8 use four scalar accumulators).  Executed by ONE lane over an LDS/global row.
+__device__ inline float ddn_aten_sum(const float *x, int n) {
+    if (n < 8) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        int q = n / 4;
+        for (int i = 0; i < q; ++i)
+            for (int k = 0; k < 4; ++k) a[k] = a[k] + x[4 * i + k];
+        for (int i = 4 * q; i < n; ++i) a[0] = a[0] + x[i];
+        return ((a[0] + a[1]) + a[2]) + a[3];
+    }
+    float P[4][8];
+    int vs = n / 8, q = vs / 4;
+    for (int k = 0; k < 4; ++k)
+        for (int l = 0; l < 8; ++l) P[k][l] = 0.0f;
+    for (int i = 0; i < q; ++i)
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < 8; ++l) P[k][l] = P[k][l] + x[(4 * i + k) * 8 + l];
+    for (int i = 4 * q; i < vs; ++i)
+        for (int l = 0; l < 8; ++l) P[0][l] = P[0][l] + x[i * 8 + l];
+    float acc = 0.0f;
+    for (int i = 8 * vs; i < n; ++i) acc = acc + x[i];
+    for (int l = 0; l < 8; ++l) acc = acc + (((P[0][l] + P[1][l]) + P[2][l]) + P[3][l]);
+    return acc;
+}
+
+// Same order, but the 8 vector lanes are 8 GPU lanes (lane l < 8 owns vector lane l); the final
+// lane-0..7 chain runs on lane 0 after a gather.  Used where a whole wave is available.
+__device__ inline float ddn_aten_sum_wave(const float *x, int n, int lane) {
+    if (n < 8) {
+        float r = 0.0f;
+        if (lane == 0) r = ddn_aten_sum(x, n);
+        return __shfl(r, 0);
+    }
+    int vs = n / 8, q = vs / 4;
+    float p = 0.0f;
+    if (lane < 8) {
+        float P0 = 0.f, P1 = 0.f, P2 = 0.f, P3 = 0.f;
+        for (int i = 0; i < q; ++i) {
+            P0 = P0 + x[(4 * i + 0) * 8 + lane];
+            P1 = P1 + x[(4 * i + 1) * 8 + lane];
+            P2 = P2 + x[(4 * i + 2) * 8 + lane];
+            P3 = P3 + x[(4 * i + 3) * 8 + lane];
+        }
+        for (int i = 4 * q; i < vs; ++i) P0 = P0 + x[i * 8 + lane];
+        p = ((P0 + P1) + P2) + P3;
+    }
+    float acc = 0.0f;
+    if (lane == 0)
+        for (int i = 8 * vs; i < n; ++i) acc = acc + x[i];
+    for (int l = 0; l < 8; ++l) {
+        float pl = __shfl(p, l);
+        acc = acc + pl;
+    }
+    return __shfl(acc, 0);
+}
