@@ -118,7 +118,7 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_fwd_kernel(const floa
         }
     };
     load_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, true);  // xyz: dead again after layer 0
-    auto io = [&](int row0) { return X3TileIO{acts, bits, nullptr, (size_t)ld, (size_t)m, row0}; };
+    auto io = [&](int row0) { return x3_tile_io(acts, bits, nullptr, ld, m, h, row0); };
     using PL = X3FwdPlan;
     // parity of the LDS buffer holding a layer's first stage: layers 0..8 have an even number of stages (2, 4, 4, 4, 4, 8,
     // 4, 4, 4) so layers 0..9 start in buffer 0; the dir layer has 5, so the heads start in buffer 1
@@ -155,7 +155,10 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_fwd_kernel(const floa
 #ifndef X3_PFD
 #define X3_PFD 6  // weight pieces in flight per wave (inference)
 #endif
-#define X3_PFD_TRAIN 14  // vmcnt retires in order: the staging ring must also cover the acknowledgement of the activation stores
+#ifndef X3_PFD_TRAIN
+#define X3_PFD_TRAIN 14
+#endif
+// vmcnt retires in order: the staging ring must also cover the acknowledgement of the activation stores
 
 DDN_EXPORT int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head, float *raw, long M,
                                      ddnerf_stream_t stream) {

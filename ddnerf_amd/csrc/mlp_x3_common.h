@@ -134,13 +134,29 @@ __device__ __forceinline__ const bf16x8 &bsrc(const bf16x8 (&H)[16], const bf16x
 //           transposed into out (the layer's pre-activation gradient)
 __device__ __forceinline__ constexpr int x3_tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+#ifdef X3_PLAIN_STORES
+#define X3_STORE(v, p) (*(p) = (v))
+#else
+#define X3_STORE(v, p) __builtin_nontemporal_store(v, p)  // streaming data must not evict the weight images from L2
+#endif
+
+// Addresses are split into a uniform part (row of the tile x ld: scalar registers) and a per-lane 32-bit element offset
+// fixed for the whole kernel, so that every tile store / sign-word access is one saddr-form instruction -- computing
+// row * ld + col per lane in 64-bit VALU arithmetic had doubled the kernel's VALU instruction count.
 struct X3TileIO {
     float *out;
     unsigned short *bits_out;
     const unsigned short *bits_in;
-    size_t ld, col;
-    int row0;  // row of the layer's block 0 in `out` (a multiple of 32)
+    size_t ld;
+    unsigned lane_f32;  // 4 h ld + col: element offset of this lane inside a tile's first row group (tile rows are
+                        // (r & 3) + 8 (r >> 2) + 4 h: the lane half selects rows +4)
+    unsigned lane_u16;  // h ld + col: this lane's sign word inside a tile's pair of word rows
+    int row0;           // row of the layer's block 0 in `out` (a multiple of 32)
 };
+__device__ __forceinline__ X3TileIO x3_tile_io(float *out, unsigned short *bits_out, const unsigned short *bits_in, long ld,
+                                               long col, int h, int row0) {
+    return X3TileIO{out, bits_out, bits_in, (size_t)ld, (unsigned)(4 * h * ld + col), (unsigned)(h * ld + col), row0};
+}
 
 // One stage: NBLK 32-row slices out of LDS buffer `cur`.  The statement order IS the schedule: a 32x32x16 MFMA occupies
 // the matrix pipe for 32 cycles but the wave's issue port for 4, so the rest of a k-step is dealt into the three
@@ -197,7 +213,7 @@ __device__ __forceinline__ void x3_stage_compute(const char *__restrict__ cur, c
     auto fetch_bits = [&](auto bc) {  // MODE 2: the sign word of block b's tile (requested a whole block ahead of its use)
         constexpr int b = decltype(bc)::value;
         if constexpr (MODE == 2 && ACT)
-            bits[b % 3] = __builtin_nontemporal_load(io.bits_in + ((size_t)tile_index(b) * 2 + h) * io.ld + io.col);
+            bits[b % 3] = __builtin_nontemporal_load(io.bits_in + (size_t)tile_index(b) * 2 * io.ld + io.lane_u16);
     };
     auto repack = [&](auto pbc, auto uc) {  // unit u (registers 2u, 2u+1) of the tile of block pb -> one hi pair + one lo pair
         constexpr int pb = decltype(pbc)::value, u = decltype(uc)::value;
@@ -212,21 +228,25 @@ __device__ __forceinline__ void x3_stage_compute(const char *__restrict__ cur, c
                 x0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x0), 0));
                 x1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x1), 0));
             }
-            if constexpr (ACT && MODE == 2) {
-                x0 = (bits[pb % 3] >> (2 * u)) & 1u ? x0 : 0.0f;
-                x1 = (bits[pb % 3] >> (2 * u + 1)) & 1u ? x1 : 0.0f;
+            if constexpr (ACT && MODE == 2) {  // x & -(bit): a sign-extended 1-bit field extract and an AND per value
+                const int w = (int)bits[pb % 3];
+                x0 = __builtin_bit_cast(float, __builtin_bit_cast(int, x0) & ((w << (31 - 2 * u)) >> 31));
+                x1 = __builtin_bit_cast(float, __builtin_bit_cast(int, x1) & ((w << (30 - 2 * u)) >> 31));
             }
             if constexpr (MODE != 0) {
-                const int row = io.row0 + 32 * (B0 + pb);
-                __builtin_nontemporal_store(x0, io.out + (size_t)(row + x3_tile_row(2 * u, h)) * io.ld + io.col);
-                __builtin_nontemporal_store(x1, io.out + (size_t)(row + x3_tile_row(2 * u + 1, h)) * io.ld + io.col);
+                // uniform tile base + one of 16 uniform row offsets (common subexpressions across all tiles) + the lane part
+                float *tile = io.out + (size_t)(io.row0 + 32 * (B0 + pb)) * io.ld;
+                X3_STORE(x0, tile + (size_t)x3_tile_row(2 * u, 0) * io.ld + io.lane_f32);
+                X3_STORE(x1, tile + (size_t)x3_tile_row(2 * u + 1, 0) * io.ld + io.lane_f32);
             }
             if constexpr (MODE == 1) {
-                const unsigned two = (x0 > 0.0f ? 1u : 0u) | (x1 > 0.0f ? 2u : 0u);
-                bits[pb % 3] = u == 0 ? two : (bits[pb % 3] | (two << (2 * u)));
+                // value > 0 <=> its bit pattern >= 1 (the values are >= +0 after the ReLU; layers without one never read
+                // their sign words): min(bits, 1) is the sign bit, one shift-or files it
+                const unsigned p0 = min(__builtin_bit_cast(unsigned, x0), 1u), p1 = min(__builtin_bit_cast(unsigned, x1), 1u);
+                bits[pb % 3] = u == 0 ? (p0 | (p1 << 1)) : (bits[pb % 3] | (p0 << (2 * u)) | (p1 << (2 * u + 1)));
                 if constexpr (u == 7)
                     __builtin_nontemporal_store((unsigned short)bits[pb % 3],
-                                                io.bits_out + ((size_t)tile_index(pb) * 2 + h) * io.ld + io.col);
+                                                io.bits_out + (size_t)tile_index(pb) * 2 * io.ld + io.lane_u16);
             }
             unsigned hw, lw;
             split_pair(x0, x1, hw, lw);

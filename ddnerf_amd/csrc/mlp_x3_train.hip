@@ -84,7 +84,10 @@ DDN_EXPORT int ddnerf_mlp_x3_pack_t(const float *params, int depth_head, void *p
     return ddn_launch_status();
 }
 
-#define X3_PFD_BWD 14  // the staging ring also has to cover the sign-word loads and the delta stores (vmcnt is in order)
+#ifndef X3_PFD_BWD
+#define X3_PFD_BWD 14
+#endif
+// the staging ring also has to cover the sign-word loads and the delta stores (vmcnt is in order)
 
 template <bool DEPTH>
 __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_bwd_data_kernel(const float *__restrict__ g_raw,
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_bwd_data_kernel(const
         for (int r = 0; r < 16; ++r)
             __builtin_nontemporal_store(r < 4 ? a[r & 3] : 0.0f, deltas + (size_t)(ROW_X + x3_tile_row(r, h)) * ld + m);
     }
-    auto io = [&](int row0) { return X3TileIO{deltas, nullptr, bits, (size_t)ld, (size_t)m, row0}; };
+    auto io = [&](int row0) { return x3_tile_io(deltas, nullptr, bits, ld, m, h, row0); };
     using PL = X3BwdPlan;
     constexpr int PFD = X3_PFD_BWD;
     // LDS buffer parity of a step's first stage: d0 has one stage (buffer 0), d1 three (starts in 1), then every step has
