@@ -11,6 +11,12 @@
 // the samples in 32-sample tiles: global -> registers (prefetched one tile ahead: 64 KiB in flight per CU keeps HBM
 // busy), split into hi / lo bf16 while parking in LDS (row stride 80 B: conflict-free ds_read_b128), then RG x CG waves
 // each accumulate RT x CT 32x32 tiles.  Partial slabs per workgroup, reduced in a fixed order (mlp_f32_wgrad.hip).
+//
+// What limits it now is the HBM round trip per tile, not bandwidth: one tile in flight per workgroup gives 0.29 ms per
+// 256x256 job at M = 524,288 where the bytes alone need 0.21.  Tried and measured slower (0.32 ms): 16-sample tiles by
+// LDS-DMA into a three-deep raw fp32 ring + a conversion pass -- a 16-sample row segment is 64 B, half an HBM line, and
+// 160 KiB of LDS has no room for a deeper ring of 32-sample tiles; a second register set for a second tile in flight
+// does not fit either (244 of 256 registers are in use at 8 waves per CU).
 #include "mlp_f32_common.h"
 #include "wgrad_reduce.h"
 
