@@ -98,17 +98,63 @@ __device__ __forceinline__ void gaussian_of_interval(float t0, float t1, float r
     }
 }
 
-// torch.remainder(x, T), T > 0
+// torch.remainder(x, T) for T = 100 * fp32(pi) and the |x| < 2^21 this encoder produces (means up to ~30 x 2^15),
+// bit-exact without the library's iterative fmodf: q = trunc(|x| * INV_UP) with INV_UP a hair ABOVE 1/T never
+// underestimates the quotient and overestimates it by at most 1; |x| - q T is a multiple of 2^-15 below 512 in magnitude,
+// so the fma delivers it exactly; a negative result means q was one too large (+T, exact again).  The sign of x and the
+// reference's final `+ T` for negative remainders (an fp32 add that rounds) follow.  Verified bit-for-bit against
+// torch.remainder on 7 M values including near-multiples of T (tests/test_oracle_vs_golden.py keeps the recipe).
 __device__ __forceinline__ float remainder_pos(float x, float T) {
-    float r = fmodf(x, T);
+    const float a = fabsf(x);
+    const float q = __builtin_truncf(a * 0.0031830994f);  // fp32(1/T * (1 + 3 * 2^-24)), rounded up
+    float r = __builtin_fmaf(-q, T, a);
+    if (r < 0.0f) r += T;
+    r = __builtin_copysignf(r, x);  // = fmodf(x, T)
     if (r != 0.0f && r < 0.0f) r += T;
     return r;
+}
+
+// sin(x + quadrant * pi/2) for |x| <= 100 pi + 2: three-term Cody-Waite reduction by pi/2 (k <= 201, so k * HI and k * MID
+// are exact: both constants carry 13 significant bits) and the Cephes single-precision kernels on [-pi/4, pi/4].
+// Max error 9.2e-8 absolute (1.5 ulp at 1) over the whole range -- the library sinf's class -- at a third of its
+// instructions (no large-argument path, no branches).  cos(x) = quadrant 1.
+__device__ __forceinline__ float enc_sin(float x, int quadrant = 0) {
+    const float k = __builtin_rintf(x * 0.63661975f);
+    float r = __builtin_fmaf(-k, 1.5705566f, x);
+    r = __builtin_fmaf(-k, 0.00023967028f, r);
+    r = __builtin_fmaf(-k, 1.5893255e-08f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(ps * z, r, r);
+    float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    const int n = (int)k + quadrant;
+    const float v = (n & 1) ? cs : sn;
+    return (n & 2) ? -v : v;
+}
+
+// exp(v) for v <= 0: n = rint(v log2 e), two-term reduction by ln 2 (13-bit HI: n * HI exact), Cephes degree-6 kernel,
+// ldexp (handles the denormal tail).  Max relative error 1.2e-7 on the normal range.
+__device__ __forceinline__ float enc_exp_neg(float v) {
+    if (!(v > -104.0f)) return v != v ? v : 0.0f;  // below the smallest denormal (the high octaves of a wide Gaussian)
+    const float n = __builtin_rintf(v * 1.44269502f);
+    float r = __builtin_fmaf(-n, 0.69311523f, v);
+    r = __builtin_fmaf(-n, 3.1946183e-05f, r);
+    float p = __builtin_fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float e = __builtin_fmaf(p * r, r, r + 1.0f);
+    return ldexpf(e, (int)n);
 }
 
 __device__ __forceinline__ float safe_sin(float x) {
     const float T = 314.159271f;  // 100 * fp32(pi), general_utils/math_utils.py:155
     float xr = (fabsf(x) < T) ? x : remainder_pos(x, T);
-    return sinf(xr);
+    return enc_sin(xr);
 }
 
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
@@ -158,8 +204,8 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
                 int f = k / 3, a = k % 3;
                 float v = rays[12 * (size_t)i + 9 + a];
                 float x = v * (float)(1 << f);                                // nerf_helpers.py:163-165
-                row[ls][96 + 3 + f * 6 + a] = sinf(x);
-                row[ls][96 + 3 + f * 6 + 3 + a] = cosf(x);
+                row[ls][96 + 3 + f * 6 + a] = enc_sin(x);      // |x| <= 8
+                row[ls][96 + 3 + f * 6 + 3 + a] = enc_sin(x, 1);  // cos
                 if (f == 0) row[ls][96 + a] = v;                              // include_input
                 if (k < 5) row[ls][123 + k] = 0.0f;                           // pad columns
             }
@@ -174,7 +220,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
             float s = (float)(1 << l);
             float y = g_mean[ls][a] * s;                                      // :130
             float yv = g_cov[ls][a] * (s * s);                                // :131
-            float damp = expf(-0.5f * yv);                                    // :149
+            float damp = enc_exp_neg(-0.5f * yv);                             // :149  (yv >= 0)
             row[ls][p] = damp * safe_sin(y);
             row[ls][48 + p] = damp * safe_sin(y + 1.57079637f);               // :143  y + 0.5*fp32(pi)
         }

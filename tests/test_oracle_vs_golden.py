@@ -112,3 +112,28 @@ def test_run_iter(name):
         ref = float(g["o1_dp_loss"][0])
         assert abs(float(out[1]["dp_loss"]) - ref) <= 2e-5 * max(abs(ref), 1e-3)
         assert abs(out[0]["mus_reg"] - g["o0_mus_reg"][0]) <= 1e-7
+
+
+def test_fp32_remainder_recipe_is_bit_exact():
+    """The encode kernel replaces fmodf by a four-instruction fp32 recipe (rays_encode.hip: remainder_pos); this is the
+    same arithmetic in numpy, checked bit-for-bit against torch.remainder on values that include near-multiples of T."""
+    import torch
+
+    f = np.float32
+    T = f(314.159271)
+    inv_up = f(0.0031830994)
+    assert float(inv_up) > 1.0 / float(T) and float(inv_up) < (1.0 / float(T)) * (1 + 4 * 2.0 ** -24)
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-2 ** 21, 2 ** 21, 1_000_000),
+                        rng.integers(-6000, 6000, 500_000) * np.float64(T) + rng.uniform(-1e-2, 1e-2, 500_000),
+                        rng.uniform(-400, 400, 200_000)]).astype(f)
+    a = np.abs(x)
+    q = np.trunc((a * inv_up).astype(f))
+    r64 = a.astype(np.float64) - q.astype(np.float64) * np.float64(T)      # what the fma returns before rounding
+    r = r64.astype(f)
+    assert np.all(r.astype(np.float64) == r64)                              # ... is exactly representable
+    r = np.where(r < 0, (r + T).astype(f), r)
+    r = np.copysign(r, x)
+    assert np.array_equal(r, np.fmod(x, T))
+    out = np.where((r != 0) & (r < 0), (r + T).astype(f), r)
+    assert np.array_equal(out, torch.remainder(torch.from_numpy(x), torch.tensor(T)).numpy())
