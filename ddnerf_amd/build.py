@@ -35,23 +35,29 @@ def _stale(target, deps):
     return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_f32_common.h"), os.path.join(CSRC, "wgrad_reduce.h"), os.path.join(CSRC, "mlp_bf16_common.h"), os.path.join(CSRC, "mlp_x3_common.h"), os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
-    objs = []
+def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    hdrs += [os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
+    objs, todo = [], []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         o = s[:-4] + ".o"
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + COMMON + extra + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-    if force or _stale(SO, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+            todo.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+
+    if todo:  # the two big MFMA kernels take about a minute each: compile the translation units side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 1, 8)) as pool:
+            list(pool.map(run, todo))
+    if force or _stale(SO, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
     return SO
 
 
