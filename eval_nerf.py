@@ -17,6 +17,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from ddnerf_amd import data, schedules  # noqa: E402
+from ddnerf_amd import metrics  # noqa: E402
 from ddnerf_amd.cfgnode import CfgNode  # noqa: E402
 from models import models  # noqa: E402
 
@@ -62,6 +63,12 @@ def eval_model(basedir, checkpoint_name="checkpoint", extract_ptc=False, save_im
             v = schedules.mse2psnr(float(torch.nn.functional.mse_loss(out[lvl]["rgb"], img)))
             results[i][name] = v
             summary[name].append(v)
+        if min(img.shape[0], img.shape[1]) >= 7:  # eval_nerf.py:153-160 (SSIM on the grey images; LPIPS needs AlexNet weights)
+            for lvl, name in ((0, "coarse"), (1, "fine")):
+                v1, v2 = metrics.calc_ssim(out[lvl]["rgb"], img)
+                for key, v in (("ssim_%s_v1" % name, v1), ("ssim_%s_v2" % name, v2)):
+                    results[i][key] = v
+                    summary[key].append(v)
         print("Avg time per image: %s" % (sum(times) / (i + 1)))
     with open(os.path.join(savedir, "results.txt"), "w") as f:  # validation_utils/visualization.py:137-150
         f.write("summary:\n")

@@ -55,4 +55,4 @@ def test_train_checkpoint_resume_eval(tmp_path):
     found = [os.path.join(d, f) for d, _, fs in os.walk(logdir) for f in fs if f == "results.txt"]
     assert found, "eval_nerf.py wrote no results.txt"
     txt = open(found[0]).read()
-    assert "psnr_fine" in txt and "summary" in txt
+    assert "psnr_fine" in txt and "summary" in txt and "ssim_fine_v2" in txt
