@@ -56,3 +56,9 @@ def test_train_checkpoint_resume_eval(tmp_path):
     assert found, "eval_nerf.py wrote no results.txt"
     txt = open(found[0]).read()
     assert "psnr_fine" in txt and "summary" in txt and "ssim_fine_v2" in txt
+
+    _run([os.path.join(ROOT, "render_video.py"), "--logdir", str(logdir), "--max_frames", "2", "--save_images"], str(tmp_path))
+    frames = sorted(os.listdir(logdir / "video" / "frames"))
+    assert frames == ["0000.png", "0001.png"] and os.path.exists(logdir / "video" / "disparity" / "0001.png")
+    from PIL import Image
+    assert Image.open(logdir / "video" / "frames" / "0000.png").size == (48, 24)        # RGB | disparity side by side
