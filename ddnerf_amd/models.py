@@ -241,21 +241,25 @@ class DDNerfModel(GeneralMipNerfModel):
                 dp = F.dp_loss(t_vals.detach(), t_vals_0.detach(), weights.detach(), weights_0, mus_0, sigmas_0,
                                head["left"].detach(), head["part"].detach(), str(cfg.dataset.type).lower() == "blender")
                 dp_loss = (dp * (t_vals.shape[1] - 1) + mus_reg + sig_reg).unsqueeze(0)          # :287-289
-            if mus is not None:                                                                  # :292-295
-                # one stream compaction (a single host sync) serves the three logging-only records
-                with torch.no_grad():
-                    pdf = weights / torch.sum(weights, dim=-1, keepdim=True)
-                    sel = torch.nonzero((pdf > 0.1).reshape(-1)).squeeze(1)
-                mus_to_record = mus.reshape(-1)[sel]
-                sigmas_to_record = sigmas.reshape(-1)[sel]
-                ssig_to_record = smoothed_sigmas.reshape(-1)[sel]
-            # level 1 records the stale level-0 tensors under the level-0 mask, as the reference does (:297-300)
+            # level 1 records the stale level-0 tensors under the level-0 mask, as the reference does (:297-300); the
+            # three logging-only records are filled in below, after the fine pass has been enqueued
             ret[i] = {"rgb": c["rgb_map"], "disp": c["disp"], "acc": c["acc"], "weights": weights, "depth": c["depth"],
-                      "mus": mus_to_record, "sigmas": sigmas_to_record, "dp_loss": dp_loss,
-                      "corrected_disp_map": c["cdisp"], "smoothed_sigmas": ssig_to_record}
+                      "mus": None, "sigmas": None, "dp_loss": dp_loss,
+                      "corrected_disp_map": c["cdisp"], "smoothed_sigmas": None}
             if i == 0:
                 ret[i]["mus_loss"] = mus_loss.unsqueeze(0)
                 ret[i]["sig_loss"] = sig_loss.unsqueeze(0)
                 ret[i]["mus_reg"] = mus_reg.unsqueeze(0)
                 ret[i]["sig_reg"] = sig_reg.unsqueeze(0)
+        # models/models.py:292-295: mus / sigmas / smoothed sigmas where the level-0 pdf exceeds 0.1.  Boolean indexing
+        # has a data-dependent size, i.e. a host sync: ONE stream compaction serves the three records, and it comes last
+        # so that the CPU has already issued the whole fine pass when it blocks (in the middle of the chunk it drained
+        # the queue and the GPU idled while the fine pass was being launched).
+        with torch.no_grad():
+            pdf = weights_0 / torch.sum(weights_0, dim=-1, keepdim=True)
+            sel = torch.nonzero((pdf > 0.1).reshape(-1)).squeeze(1)
+        rec = {"mus": mus_0.reshape(-1)[sel], "sigmas": sigmas_0.reshape(-1)[sel],
+               "smoothed_sigmas": smoothed_sigmas.reshape(-1)[sel]}
+        for i in range(2):
+            ret[i].update(rec)
         return ret
