@@ -28,6 +28,10 @@ class TorchRng:
     def randn(self, shape, device):
         return torch.randn(shape, dtype=torch.float32, device=device)
 
+    def randn_scaled(self, shape, device, std):
+        """randn * std in ONE kernel (the generator applies the scale: same values as the two-step form)"""
+        return torch.empty(shape, dtype=torch.float32, device=device).normal_(0.0, float(std))
+
 
 _const_cache = {}
 
@@ -139,8 +143,9 @@ class GeneralMipNerfModel(torch.nn.Module):
 
     def _noise(self, n, S, mode, device):
         std = self._mode_cfg(mode).radiance_field_noise_std
-        if std > 0.0:
-            return self.rng.randn((n, S), device) * std  # volume_rendering_utils.py:29-37
+        if std > 0.0:  # volume_rendering_utils.py:29-37
+            scaled = getattr(self.rng, "randn_scaled", None)
+            return scaled((n, S), device, std) if scaled is not None else self.rng.randn((n, S), device) * std
         return None
 
     def run_network(self, ray_batch, t_vals, network, mode):
