@@ -29,6 +29,8 @@ _SIGS = {
     "ddnerf_mlp_x3_packed_t_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_x3_pack_t": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_x3_backward_data": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_dd_records_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddnerf_dd_records": (C.c_int, [c_fp] * 4 + [C.c_int, C.c_int] + [c_fp] * 5 + [c_fp]),
     "ddnerf_dd_head_workspace_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddnerf_dd_head": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_float, C.c_float] + [c_fp] * 9 + [c_fp]),
     "ddnerf_composite_forward": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int] + [c_fp] * 7 + [c_fp]),

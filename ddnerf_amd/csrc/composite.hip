@@ -354,3 +354,95 @@ DDN_EXPORT int ddnerf_dd_head_backward(const float *raw6, int n, int nc, float d
                        count, n, dist_reg, g_mus, g_sigmas, g_scal, g_raw6);
     return ddn_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// DD records (models/models.py:292-295): mus / sigmas / smoothed sigmas of the coarse bins whose level-0 pdf
+// w / sum(w) exceeds 0.1, as flat tensors in row-major order (what `x[pdf > 0.1]` returns).  The sizes are data
+// dependent; three small kernels replace the dozen torch launches of sum, divide, compare, nonzero and three gathers:
+//   count: wave per ray -- the row sum in torch.sum's order, IEEE divide, one flag byte per bin, the row's count
+//   scan : one block    -- exclusive scan of the row counts, the total
+//   write: wave per ray -- ordered writes of the three records
+// The caller allocates the outputs at capacity n * nc and reads `total` when it needs the shapes (its only host sync).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dd_records_count_kernel(const float *__restrict__ w, int n, int nc,
+                                                              unsigned char *__restrict__ flags, int *__restrict__ counts) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const float *row = w + (size_t)ray * nc;
+    const float s = ddn_aten_sum_wave(row, nc, lane);
+    int cnt = 0;
+    for (int j = lane; j < nc; j += 64) {
+        const int f = (row[j] / s) > 0.1f;  // NaN (an all-zero row) compares false, like torch
+        flags[(size_t)ray * nc + j] = (unsigned char)f;
+        cnt += f;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) counts[ray] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void dd_records_scan_kernel(const int *__restrict__ counts, int n, int *__restrict__ offsets,
+                                                              int *__restrict__ total) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = tid * per, hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += counts[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = tid > 0 ? part[tid - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        offsets[i] = base;
+        base += counts[i];
+    }
+    if (tid == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(256) void dd_records_write_kernel(const unsigned char *__restrict__ flags,
+                                                              const int *__restrict__ offsets, const float *__restrict__ mus,
+                                                              const float *__restrict__ sigmas, const float *__restrict__ ssig,
+                                                              int n, int nc, float *__restrict__ out_mus,
+                                                              float *__restrict__ out_sigmas, float *__restrict__ out_ssig) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    int base = offsets[ray];
+    for (int j0 = 0; j0 < nc; j0 += 64) {
+        const int j = j0 + lane;
+        const bool f = j < nc && flags[(size_t)ray * nc + j];
+        const unsigned long long m = __ballot(f);
+        if (f) {
+            const int dst = base + __popcll(m & ((1ull << lane) - 1ull));
+            const size_t src = (size_t)ray * nc + j;
+            out_mus[dst] = mus[src];
+            out_sigmas[dst] = sigmas[src];
+            out_ssig[dst] = ssig[src];
+        }
+        base += __popcll(m);
+    }
+}
+
+DDN_EXPORT size_t ddnerf_dd_records_workspace_bytes(int n, int nc) {
+    return (size_t)n * nc + (size_t)(2 * n + 1) * sizeof(int) + 16;
+}
+
+DDN_EXPORT int ddnerf_dd_records(const float *weights, const float *mus, const float *sigmas, const float *ssig, int n, int nc,
+                                 float *out_mus, float *out_sigmas, float *out_ssig, int *total, void *workspace,
+                                 ddnerf_stream_t stream) {
+    DDN_REQUIRE(weights && mus && sigmas && ssig && out_mus && out_sigmas && out_ssig && total && workspace, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    int *counts = (int *)workspace, *offsets = counts + n;
+    unsigned char *flags = (unsigned char *)(offsets + n + 1);
+    dim3 grid((unsigned)((n + 3) / 4));
+    hipLaunchKernelGGL(dd_records_count_kernel, grid, dim3(256), 0, st, weights, n, nc, flags, counts);
+    hipLaunchKernelGGL(dd_records_scan_kernel, dim3(1), dim3(1024), 0, st, counts, n, offsets, total);
+    hipLaunchKernelGGL(dd_records_write_kernel, grid, dim3(256), 0, st, flags, offsets, mus, sigmas, ssig, n, nc, out_mus,
+                       out_sigmas, out_ssig);
+    return ddn_launch_status();
+}

@@ -257,14 +257,12 @@ class DDNerfModel(GeneralMipNerfModel):
                 ret[i]["mus_reg"] = mus_reg.unsqueeze(0)
                 ret[i]["sig_reg"] = sig_reg.unsqueeze(0)
         # models/models.py:292-295: mus / sigmas / smoothed sigmas where the level-0 pdf exceeds 0.1.  Boolean indexing
-        # has a data-dependent size, i.e. a host sync: ONE stream compaction serves the three records, and it comes last
+        # has a data-dependent size, i.e. a host sync: ONE stream compaction (ops.dd_records) serves the three records, and it comes last
         # so that the CPU has already issued the whole fine pass when it blocks (in the middle of the chunk it drained
         # the queue and the GPU idled while the fine pass was being launched).
         with torch.no_grad():
-            pdf = weights_0 / torch.sum(weights_0, dim=-1, keepdim=True)
-            sel = torch.nonzero((pdf > 0.1).reshape(-1)).squeeze(1)
-        rec = {"mus": mus_0.reshape(-1)[sel], "sigmas": sigmas_0.reshape(-1)[sel],
-               "smoothed_sigmas": smoothed_sigmas.reshape(-1)[sel]}
+            r_mus, r_sig, r_ssig = ops.dd_records(weights_0, mus_0, sigmas_0, smoothed_sigmas)
+        rec = {"mus": r_mus, "sigmas": r_sig, "smoothed_sigmas": r_ssig}
         for i in range(2):
             ret[i].update(rec)
         return ret

@@ -161,6 +161,21 @@ def dd_head(raw6, smooth, dist_reg):
     return d
 
 
+def dd_records(weights, mus, sigmas, ssig):
+    """models/models.py:292-295 -> (mus, sigmas, smoothed_sigmas) of the bins with pdf = w / sum(w) > 0.1, flat row-major.
+    Reads the data-dependent length from the device (one host sync) -- call it when nothing else is left to enqueue."""
+    weights, mus, sigmas, ssig = (_f32c(t, "records") for t in (weights, mus, sigmas, ssig))
+    n, nc = weights.shape
+    dev = weights.device
+    outs = [torch.empty(n * nc, dtype=torch.float32, device=dev) for _ in range(3)]
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.lib().ddnerf_dd_records_workspace_bytes(n, nc), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().ddnerf_dd_records(_ptr(weights), _ptr(mus), _ptr(sigmas), _ptr(ssig), n, nc, *[_ptr(o) for o in outs],
+                                            _ptr(total), _ptr(ws), _stream()), "ddnerf_dd_records")
+    k = int(total.item())
+    return tuple(o[:k] for o in outs)
+
+
 def composite_forward(raw, t_vals, rays, noise=None, mus=None, white_bkgd=False, blender=True, want_rgb=False):
     """general_utils/volume_rendering_utils.py:6-85.  raw [n,S,4|6]"""
     raw, t_vals, rays = _f32c(raw, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays")

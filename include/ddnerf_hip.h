@@ -177,6 +177,14 @@ int ddnerf_composite_backward(const float *raw, int ldr, const float *t_vals, co
 int ddnerf_dd_head_backward(const float *raw6, int n, int nc, float dist_reg, const float *g_mus, const float *g_sigmas,
                             const float *g_scal, float *g_raw6, ddnerf_stream_t stream);
 
+/* The logging records of models/models.py:292-295: mus / sigmas / smoothed sigmas where the level-0 pdf w / sum(w)
+ * exceeds 0.1, flat in row-major order (what boolean indexing returns).  Outputs have capacity n*nc; *total receives the
+ * number of selected bins (device int).  workspace: ddnerf_dd_records_workspace_bytes(n, nc) bytes, 4-byte aligned. */
+size_t ddnerf_dd_records_workspace_bytes(int n, int nc);
+int ddnerf_dd_records(const float *weights, const float *mus, const float *sigmas, const float *ssig, int n, int nc,
+                      float *out_mus, float *out_sigmas, float *out_ssig, int *total, void *workspace,
+                      ddnerf_stream_t stream);
+
 /* backward of estimate_dp_loss w.r.t. (w0, mus0, sig0); g_loss[0] = upstream gradient of the scalar loss.
  * workspace as for the forward. */
 int ddnerf_dp_loss_backward(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,

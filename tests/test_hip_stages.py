@@ -79,6 +79,21 @@ def test_mlp_f32_ragged_and_large(ops):
         assert maxerr(raw, ref) <= 2e-6 * max(1.0, np.abs(ref).max()), (M, depth)
 
 
+def test_dd_records_match_boolean_indexing(ops):
+    """ops.dd_records (three small kernels) against the reference's expression pdf = w / w.sum(-1); x[pdf > 0.1] evaluated by
+    torch on the CPU (ATen's summation order), incl. an all-zero row (NaN pdf: nothing selected) and ragged widths"""
+    rng = np.random.default_rng(8)
+    for n, nc in ((37, 64), (5, 16), (130, 33), (3, 1)):
+        w = (rng.random((n, nc)) ** 6).astype(np.float32)
+        w[n // 2] = 0.0
+        mus, sig, ssig = (rng.random((n, nc)).astype(np.float32) for _ in range(3))
+        wt = torch.from_numpy(w)
+        mask = (wt / torch.sum(wt, dim=-1, keepdim=True)) > 0.1
+        got = ops.dd_records(dev(w), dev(mus), dev(sig), dev(ssig))
+        for g, src in zip(got, (mus, sig, ssig)):
+            assert np.array_equal(host(g), torch.from_numpy(src)[mask].numpy()), (n, nc)
+
+
 def test_mlp_x3_fp32_class_accuracy(ops):
     """The bf16x3 kernel (exact hi/lo operand splits, three MFMAs per product) against the oracle's fp32 evaluation:
     ragged sizes, both heads, default and sharpened weights.  Bar: 2e-5 of the output scale -- 30x looser than the exact
