@@ -16,7 +16,8 @@
 // 256x256 job at M = 524,288 where the bytes alone need 0.21.  Tried and measured slower (0.32 ms): 16-sample tiles by
 // LDS-DMA into a three-deep raw fp32 ring + a conversion pass -- a 16-sample row segment is 64 B, half an HBM line, and
 // 160 KiB of LDS has no room for a deeper ring of 32-sample tiles; a second register set for a second tile in flight
-// does not fit either (244 of 256 registers are in use at 8 waves per CU).
+// does not fit either (244 of 256 registers are in use at 8 waves per CU); two 256-thread workgroups per CU, each with
+// half of the out-rows and its own tile pipeline, made a training step 1.4 ms slower.
 #include "mlp_f32_common.h"
 #include "wgrad_reduce.h"
 
