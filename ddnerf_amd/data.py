@@ -44,17 +44,22 @@ def load_blender(basedir, half_res=False, testskip=1):
         skip = 1 if (s == "train" or testskip == 0) else testskip
         n0 = len(imgs)
         for frame in meta["frames"][::skip]:
-            im = Image.open(os.path.join(basedir, frame["file_path"] + ".png")).convert("RGBA")
+            im = np.asarray(Image.open(os.path.join(basedir, frame["file_path"] + ".png")).convert("RGBA"), dtype=np.float32) / 255.0
             if half_res:
-                im = im.resize((im.width // 2, im.height // 2), Image.BOX)  # area averaging, like cv2.INTER_AREA
-            imgs.append(np.asarray(im, dtype=np.float32) / 255.0)
+                # the reference halves with cv2.INTER_AREA on the float RGBA array (load_blender.py:133-140): a plain 2x2 box
+                # mean per channel (PIL's own RGBA resize would premultiply by alpha)
+                h2, w2 = im.shape[0] // 2, im.shape[1] // 2
+                im = im[: 2 * h2, : 2 * w2].reshape(h2, 2, w2, 2, 4).mean((1, 3), dtype=np.float32)
+            imgs.append(im)
             poses.append(np.array(frame["transform_matrix"], dtype=np.float32))
         counts.append(counts[-1] + len(imgs) - n0)
     imgs, poses = np.stack(imgs), np.stack(poses)
     H, W = imgs.shape[1:3]
-    focal = 0.5 * W / math.tan(0.5 * float(meta["camera_angle_x"]))
+    # data_utils/load_blender.py:104-105, 128-131: focal from the FULL-resolution width, halved with the images
+    full_w = W * 2 if half_res else W
+    focal = 0.5 * full_w / math.tan(0.5 * float(meta["camera_angle_x"]))
     if half_res:
-        focal = focal / 2.0 * (imgs.shape[2] * 2 / W) if False else 0.5 * (W * 2) / math.tan(0.5 * float(meta["camera_angle_x"])) / 2.0
+        focal = focal / 2.0
     i_split = [np.arange(counts[i], counts[i + 1]) for i in range(3)]
     render_poses = np.stack([_pose_spherical(a, -30.0, 4.0) for a in np.linspace(-180, 180, 181)[:-1]])
     return imgs, poses, render_poses, (H, W, focal), i_split
