@@ -122,7 +122,7 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_fwd_kernel(const floa
     using PL = X3FwdPlan;
     // parity of the LDS buffer holding a layer's first stage: layers 0..8 have an even number of stages (2, 4, 4, 4, 4, 8,
     // 4, 4, 4) so layers 0..9 start in buffer 0; the dir layer has 5, so the heads start in buffer 1
-    x3_layer<PL, 0, 0, 1, 0, 8, true, MODE, PFD, true>(wp, lds, HAh, HAl, Xh, Xl, HAh, HAl, keep, wave, lane, io(0));
+    x3_layer<PL, 0, 0, 1, 0, 8, true, MODE, PFD, true, true>(wp, lds, HAh, HAl, Xh, Xl, HAh, HAl, keep, wave, lane, io(0));
     x3_layer<PL, 1, 1, 2, 0, 8, false, MODE, PFD, true>(wp, lds, HAh, HAl, Xh, Xl, HBh, HBl, keep, wave, lane, io(256));
     x3_layer<PL, 2, 1, 3, 0, 8, true, MODE, PFD, true>(wp, lds, HBh, HBl, Xh, Xl, HAh, HAl, keep, wave, lane, io(512));
     x3_layer<PL, 3, 1, 4, 0, 8, false, MODE, PFD, true>(wp, lds, HAh, HAl, Xh, Xl, HBh, HBl, keep, wave, lane, io(768));

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_bwd_data_kernel(const
     constexpr int PFD = X3_PFD_BWD;
     // LDS buffer parity of a step's first stage: d0 has one stage (buffer 0), d1 three (starts in 1), then every step has
     // four and starts in buffer 0
-    x3_layer<PL, 0, 10, 1, 0, 4, true, 2, PFD, true>(wp, lds, HAh, HAl, Xh, Xl, HAh, HAl, keep, wave, lane, io(ROW_DIR));
+    x3_layer<PL, 0, 10, 1, 0, 4, true, 2, PFD, true, true>(wp, lds, HAh, HAl, Xh, Xl, HAh, HAl, keep, wave, lane, io(ROW_DIR));
     x3_layer<PL, 1, 11, 2, 1, 8, false, 2, PFD, false>(wp, lds, HAh, HAl, Xh, Xl, HBh, HBl, keep, wave, lane, io(ROW_FEAT));
     x3_layer<PL, 2, 1, 3, 0, 8, true, 2, PFD, true>(wp, lds, HBh, HBl, Xh, Xl, HAh, HAl, keep, wave, lane, io(256 * 7));
     x3_layer<PL, 3, 1, 4, 0, 8, false, 2, PFD, true>(wp, lds, HAh, HAl, Xh, Xl, HBh, HBl, keep, wave, lane, io(256 * 6));
