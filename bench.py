@@ -10,7 +10,8 @@ Prints ONE JSON line on rank 0 with the metric, a `roofline` object for the domi
 forward: algorithmic FLOP per launch / mean launch duration measured with HIP events on the launch stream) and,
 at N=1, a `cpu_baseline` object (the CPU oracle timed on a bounded sample of the same workload) and a `bf16_tier`
 object and an `x3_tier` object (the same workload on the plain-bf16 and on the split-precision bf16x3 MLP kernels, each with
-its own roofline fraction against the bf16 MFMA peak).
+its own roofline fraction against the bf16 MFMA peak), and a `train_tier` object (training steps per second of the same
+workload on the fp32 and the x3 kernels).
 """
 import argparse
 import json
@@ -87,6 +88,21 @@ class KernelTimer:
     def mean_ms(self, M):
         ts = [a.elapsed_time(b) for m, a, b in self.pairs if m == M]
         return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
+
+
+def train_tier(args, mlp):
+    """Training throughput (forward + backward + Adam per step) of the same workload, from a child run of
+    `bench.py --mode train --mlp <mlp>`; reported beside the render headline, never as `value`."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--mlp", mlp, "--steps", "5", "--warmup", "2",
+           "--rays", str(args.rays), "--coarse", str(args.coarse), "--fine", str(args.fine), "--no-cpu-baseline"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"]}
 
 
 def extra_tier(args, mlp):
@@ -230,6 +246,7 @@ def main():
         if world == 1 and args.mode == "render" and args.mlp == "fp32" and not args.no_bf16_tier:
             line["x3_tier"] = extra_tier(args, "x3")
             line["bf16_tier"] = extra_tier(args, "bf16")
+            line["train_tier"] = {"fp32": train_tier(args, "fp32"), "x3": train_tier(args, "x3")}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f)
         print(json.dumps(line), flush=True)

@@ -38,6 +38,7 @@ def test_render_line_has_the_contract_fields():
     for tier, lo in (("x3_tier", 0.2), ("bf16_tier", 0.2)):
         t = d[tier]
         assert t["value"] > d["value"] and t["roofline"]["peak"] == 2500.0 and lo < t["roofline"]["frac"] < 1.0, tier
+    assert d["train_tier"]["x3"]["value"] > d["train_tier"]["fp32"]["value"] > 0
 
 
 def test_train_line():
