@@ -61,7 +61,7 @@ class _FusedMLP(torch.nn.Module):
     def flat_params(self) -> torch.Tensor:
         """The flat fp32 buffer all parameters alias (re-made if someone re-pointed a .data)."""
         first = self.layers_xyz[0].weight
-        last = list(self.parameters())[-1]
+        last = self.fc_mu_sigma.bias if self.depth_head else self.fc_rgb.bias  # registration order: the last parameter
         if (self._flat is None or first.data_ptr() != self._flat.data_ptr()
                 or last.data_ptr() + last.numel() * 4 != self._flat.data_ptr() + self._flat.numel() * 4):
             self._flatten()
