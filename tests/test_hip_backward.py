@@ -284,3 +284,62 @@ def test_training_steps_follow_reference(name, mlp_dtype):
             # single entries may sit far apart; the norm bound below is the tight one)
             assert float((mine - ref).abs().max()) <= 0.6 * steps * lr, (pfx, pname, float((mine - ref).abs().max()))
             assert float((mine - ref).norm()) <= 0.05 * float(steps * lr * np.sqrt(ref.numel())) + 1e-7, (pfx, pname)
+
+
+def test_weight_gradient_kernels_at_full_size(ops):
+    """M = 524,288 samples (the fine pass of BASELINE config 2): the split-K paths with 256 workgroups x 64 tiles that the small
+    cases never reach.  The bf16x3 and the fp32-MFMA kernels are independent implementations; both must agree with each other
+    and with a library GEMM on the same [feature][sample] operands, for a full 256 x 256 job, a ragged-input job (96 of 96
+    columns at a column offset) and a 3-row head job, including the bias sums."""
+    M = 4096 * 128
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = torch.randn(2560, M, device="cuda", generator=g)
+    deltas = torch.randn(2560, M, device="cuda", generator=g) * 1e-3
+    ws = torch.empty(ops._lib.lib().ddnerf_mlp_f32_wgrad_workspace_floats(M), dtype=torch.float32, device="cuda")
+    for drow0, n_out, arow0, n_in, used, col0, ld in ((512, 256, 256, 256, 256, 0, 256), (0, 256, 2432, 96, 96, 0, 96),
+                                                      (1280, 256, 1024, 256, 256, 96, 352), (2432, 3, 2304, 128, 128, 0, 128)):
+        outs = {}
+        for mode in ("x3", "f32"):
+            ops.WGRAD_MODE = mode
+            w = torch.zeros(n_out, ld, device="cuda")
+            b = torch.zeros(n_out, device="cuda")
+            ops.mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, used, M, w, ld, col0, b, ws)
+            outs[mode] = (w.clone(), b.clone())
+        ops.WGRAD_MODE = "x3"
+        ref_w = deltas[drow0:drow0 + n_out] @ acts[arow0:arow0 + used].T
+        ref_b = deltas[drow0:drow0 + n_out].double().sum(1).float()
+        scale = float(ref_w.abs().max())
+        for mode, (w, b) in outs.items():
+            assert float((w[:, col0:col0 + used] - ref_w).abs().max()) <= 2e-4 * scale, (mode, drow0)
+            assert float((b - ref_b).abs().max()) <= 1e-4 * float(ref_b.abs().max()) + 1e-7, (mode, drow0)
+            if col0:
+                assert float(w[:, :col0].abs().max()) == 0.0          # columns outside the job are not touched
+        assert float((outs["x3"][0] - outs["f32"][0]).abs().max()) <= 5e-5 * scale
+
+
+def test_training_kernels_at_full_size(ops):
+    """M = 262,144 samples (the coarse pass of BASELINE config 2): the x3 and the fp32 training kernels record the same
+    activations and the same deltas (up to the x3 accuracy class and ReLU-kink flips) at a size where ld, the grid and the
+    32-bit lane offsets are those of the benchmark."""
+    M, depth = 4096 * 64, True
+    sd = synthetic.make_state_dict(depth, 11, 4.0)
+    names = [n for n, _, _ in synthetic.layer_table(depth)]
+    flat = torch.from_numpy(np.concatenate([np.concatenate([sd[k + ".weight"].ravel(), sd[k + ".bias"].ravel()]) for k in names])).cuda()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    feat = torch.zeros(M, 128, device="cuda")
+    feat[:, :123] = torch.rand(M, 123, device="cuda", generator=g) * 2 - 1
+    G = torch.randn(M, 6, device="cuda", generator=g)
+    raw_f, acts_f = ops.mlp_f32_forward_train(feat, ops.mlp_f32_pack(flat, depth), depth)
+    raw_x, acts_x, bits = ops.mlp_x3_forward_train(feat, ops.mlp_x3_pack(flat, depth), depth)
+    assert float((raw_f - raw_x).abs().max()) <= 2e-5 * float(raw_f.abs().max())
+    rows = torch.cat([torch.arange(0, 2432, 37, device="cuda"), torch.arange(2432, 2555, device="cuda")])
+    a, b = acts_f[rows], acts_x[rows]
+    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    assert torch.equal(acts_f[2432:2555], acts_x[2432:2555])                      # the transposed input columns: exact copies
+    d_f = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_f, depth)
+    d_x = ops.mlp_x3_backward_data(G, ops.mlp_x3_pack_t(flat, depth), bits, depth)
+    rows = torch.cat([torch.arange(0, 2432, 41, device="cuda"), torch.arange(2432, 2438, device="cuda")])
+    a, b = d_f[rows], d_x[rows]
+    off = (a - b).abs() > 1e-4 * float(a.abs().max())
+    assert float(off.float().mean()) <= 1e-4, float(off.float().mean())            # kink flips only (measured ~1e-5)
+    assert float((a - b).norm()) <= 2e-3 * float(a.norm())
