@@ -14,7 +14,8 @@ calib = agg(os.path.join(P, "calib", "c_counter_collection.csv"))
 cal = {k: sum(v for v, _, _ in calib[k]["FETCH_SIZE"]) / len(calib[k]["FETCH_SIZE"]) for k in ("calib_rows", "calib_stream")}
 TRUE_KB = 524288 * 512 / 1024
 mfma = {}
-for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512 + 16)), ("bf16", "void mlp_bf16_fwd_kernel<false>", 524288 * (256 + 16))):
+for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512 + 16)), ("bf16", "void mlp_bf16_fwd_kernel<false>", 524288 * (256 + 16)),
+                        ("x3", "void mlp_x3_fwd_kernel<false, 0, 6>", 524288 * (512 + 16))):
     f = agg(os.path.join(P, "fetch_" + mlp, "c_counter_collection.csv"))
     w = agg(os.path.join(P, "write_" + mlp, "c_counter_collection.csv"))
     table = {}
