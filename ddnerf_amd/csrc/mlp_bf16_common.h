@@ -15,6 +15,12 @@ __host__ __device__ __forceinline__ constexpr int korder(int p) {  // packed pos
     return (p & ~15) | ((p & 3) + 4 * (((p >> 2) & 1) * 2 + ((p >> 3) & 1)));
 }
 
+// k-order of the 16x16x32 kernel (mlp_bf16.hip): inside every 32 columns, packed position 8g + e (lane group g, fragment
+// element e) holds original column 16(e>>2) + 4g + (e&3)
+__host__ __device__ __forceinline__ constexpr int korder32(int p) {  // packed position -> original column
+    return (p & ~31) | (16 * ((p >> 2) & 1) + 4 * ((p >> 3) & 3) + (p & 3));
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);

@@ -232,8 +232,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
         for (int e = tid; e < ENC_SPB * DDNERF_FEAT_LD / 2; e += 256) {
             int ls = e / (DDNERF_FEAT_LD / 2), c = (e % (DDNERF_FEAT_LD / 2)) * 2;
             if (m0 + ls < M) {
-                // bf16 rows are stored in MFMA k-order: inside every 16 columns the quads are [0,2,1,3]
-                const int cs = (c & ~15) | ((c & 3) + 4 * (((c >> 2) & 1) * 2 + ((c >> 3) & 1)));
+                // bf16 rows are stored in the MFMA k-order of the 16x16x32 MLP kernel (mlp_bf16_common.h korder32):
+                // inside every 32 columns, position 8g + e holds column 16(e>>2) + 4g + (e&3)
+                const int cs = (c & ~31) | (16 * ((c >> 2) & 1) + 4 * ((c >> 3) & 3) + (c & 3));
                 unsigned v = (unsigned)f32_to_bf16(row[ls][cs]) | ((unsigned)f32_to_bf16(row[ls][cs + 1]) << 16);
                 *(unsigned *)(feat + (m0 + ls) * DDNERF_FEAT_LD + c) = v;
             }

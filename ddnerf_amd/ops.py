@@ -143,7 +143,8 @@ def mlp_x3_forward(feat, packed, depth_head):
     return raw
 
 
-K_ORDER = [(p & ~15) | ((p & 3) + 4 * (((p >> 2) & 1) * 2 + ((p >> 3) & 1))) for p in range(FEAT_LD)]
+# packed position -> original feature column of the bf16 kernel's "k-order" (csrc/mlp_bf16_common.h korder32)
+K_ORDER = [(p & ~31) | (16 * ((p >> 2) & 1) + 4 * ((p >> 3) & 3) + (p & 3)) for p in range(FEAT_LD)]
 
 
 def dd_head(raw6, smooth, dist_reg):

@@ -78,9 +78,9 @@ int ddnerf_mlp_f32_forward(const float *feat, const float *packed, int depth_hea
                            ddnerf_stream_t stream);
 
 /* bf16-MFMA variant of the same network (bf16 operands, fp32 accumulation, fp32 biases and outputs).
- * feat: bf16 [M,128] as written by ddnerf_encode(feat_dtype=1), i.e. in MFMA "k-order": inside every 16
- * columns the four quads are stored [0,2,1,3] (the order in which an accumulator tile re-enters the next
- * layer's matrix instruction as its B operand). */
+ * feat: bf16 [M,128] as written by ddnerf_encode(feat_dtype=1), i.e. in MFMA "k-order": inside every 32
+ * columns, position 8g + e (g = 0..3, e = 0..7) holds column 16(e>>2) + 4g + (e&3) -- the order in which two
+ * 16x16 accumulator tiles re-enter the next layer's v_mfma_f32_16x16x32_bf16 as its B operand. */
 size_t ddnerf_mlp_bf16_packed_bytes(int depth_head);
 int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M,

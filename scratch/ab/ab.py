@@ -1,5 +1,6 @@
 """interleaved A/B timing of MLP-forward variants in ONE process (devices and DVFS states differ between runs).
-usage: ab.py fp32|bf16 lib1.so lib2.so ...   (each lib exports the ddnerf_mlp_* C ABI; packs with its own pack kernel)"""
+usage: ab.py fp32|bf16|x3 lib1.so[:symbol_infix] lib2.so ...   (each lib exports the ddnerf_mlp_* C ABI and packs with its own
+pack kernel; `lib.so:bf16v1` calls ddnerf_mlp_bf16v1_* instead of ddnerf_mlp_bf16_*)"""
 import ctypes as C, sys, os, statistics, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ddnerf_amd import synthetic
@@ -16,13 +17,15 @@ st = torch.cuda.current_stream().cuda_stream
 V = C.c_void_p
 runs = []
 for so in libs:
+    so, _, infix = so.partition(":")
     L = C.CDLL(so)
     if kind == "bf16":
-        L.ddnerf_mlp_bf16_packed_bytes.restype = C.c_size_t
-        packed = torch.empty(L.ddnerf_mlp_bf16_packed_bytes(0), dtype=torch.uint8, device="cuda")
-        L.ddnerf_mlp_bf16_pack.argtypes = [V, C.c_int, V, V]
-        assert L.ddnerf_mlp_bf16_pack(flat.data_ptr(), 0, packed.data_ptr(), st) == 0
-        f = L.ddnerf_mlp_bf16_forward; f.argtypes = [V, V, C.c_int, V, C.c_long, V]
+        infix = infix or "bf16"
+        pb = getattr(L, "ddnerf_mlp_%s_packed_bytes" % infix); pb.restype = C.c_size_t
+        packed = torch.empty(pb(0), dtype=torch.uint8, device="cuda")
+        pk = getattr(L, "ddnerf_mlp_%s_pack" % infix); pk.argtypes = [V, C.c_int, V, V]
+        assert pk(flat.data_ptr(), 0, packed.data_ptr(), st) == 0
+        f = getattr(L, "ddnerf_mlp_%s_forward" % infix); f.argtypes = [V, V, C.c_int, V, C.c_long, V]
         runs.append((so, lambda f=f, packed=packed: f(fb.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)))
     elif kind == "x3":
         L.ddnerf_mlp_x3_packed_bytes.restype = C.c_size_t

@@ -117,7 +117,9 @@ def test_mlp_bf16_ragged_vs_bf16_emulation(ops):
     def bf(x):
         return torch.from_numpy(np.asarray(x, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
 
-    for M, depth in ((1, True), (255, False), (257, True), (1500, False)):
+    # 70001 samples = 274 tiles of 256: more tiles than CUs, so the persistent workgroups walk on to a second tile
+    # (features prefetched during the first) and the last tile is ragged
+    for M, depth in ((1, True), (255, False), (257, True), (1500, False), (70001, True), (66000, False)):
         feat = np.zeros((M, 128), np.float32)
         feat[:, :123] = rng.uniform(-1, 1, (M, 123)).astype(np.float32)
         sd = synthetic.make_state_dict(depth, 4, 1.0)
@@ -138,8 +140,13 @@ def test_mlp_bf16_ragged_vs_bf16_emulation(ops):
         fb = torch.from_numpy(np.ascontiguousarray(feat[:, ops.K_ORDER])).to(torch.bfloat16).cuda().contiguous()
         packed = ops.mlp_bf16_pack(dev(flat_params(sd, depth)), depth)
         raw = host(ops.mlp_bf16_forward(fb, packed, depth))
+        # The kernel sums each dot product in a different order than numpy, so a pre-activation that sits on a bf16 rounding
+        # boundary may round the other way: one such flip moves an output by ~1e-4.  Bulk agreement is ~1e-8; a wrong
+        # k-permutation or tile map puts EVERY entry off by ~0.1.
         col_scale = np.maximum(np.abs(ref).max(0), 0.1)
-        assert (np.abs(raw - ref).max(0) <= 1.5e-3 * col_scale).all(), (M, depth, np.abs(raw - ref).max(0) / col_scale)   # rounding-boundary flips only
+        err = np.abs(raw - ref) / col_scale
+        assert (err <= 2e-5).mean() >= 0.97, (M, depth, (err <= 2e-5).mean())
+        assert err.max() <= 6e-3, (M, depth, err.max(0))
 
 
 @pytest.mark.parametrize("tag", ["lin", "disp", "ndc"])
