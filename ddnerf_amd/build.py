@@ -31,12 +31,41 @@ SOURCES = {
 }
 
 
+# kernels whose matrix instructions are inline asm: the compiler's assembly is scanned for dependent pairs that sit closer
+# than the wait states nobody pads (csrc/check_asm_hazards.py); a violation fails the build
+CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel"}
+
+
+def _compile_checked(cmd, src, obj, kernel, verbose):
+    import shutil
+    import tempfile
+
+    from .csrc import check_asm_hazards
+
+    tmp = tempfile.mkdtemp(prefix="ddnerf_build_")
+    try:
+        base = os.path.basename(obj)
+        c = cmd[:-1] + [os.path.join(tmp, base), "-save-temps=obj"]
+        if verbose:
+            print(" ".join(c), flush=True)
+        subprocess.check_call(c)
+        asm = os.path.join(tmp, base[:-2] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        n, bad = check_asm_hazards.check(asm, kernel)
+        if bad:
+            raise RuntimeError("%s: %d dependent instruction pairs closer than the unpadded wait states, e.g.\n%s" % (src, len(bad), bad[0]))
+        if verbose:
+            print("%s: %d MFMAs, no too-close dependent pair" % (src, n), flush=True)
+        shutil.move(os.path.join(tmp, base), obj)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _stale(target, deps):
     return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
-    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h") or h.endswith(".py")]
     hdrs += [os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
     objs, todo = [], []
     for src, extra in SOURCES.items():
@@ -47,6 +76,9 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
             todo.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
 
     def run(cmd):
+        src = os.path.basename(cmd[-3])
+        if src in CHECKED and cmd[-2] == "-o":
+            return _compile_checked(cmd, src, cmd[-1], CHECKED[src], verbose)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -1,0 +1,104 @@
+"""Build-time check of the hand-placed MFMA streams (mlp_bf16.hip).
+
+The matrix instructions of that kernel are written as inline asm (so that the accumulators stay in place), and hipcc pads
+nothing around an asm statement: the wait states between a VALU write and an MFMA that reads the register, between an
+MFMA and a VALU write to one of its sources, and between an MFMA and a reader of its result exist only because the
+written instruction order keeps such pairs far apart.  A compiler-inserted register copy next to an MFMA would break that
+silently (it did once: outputs off by 1e-3).  This script scans the compiler's assembly of the kernel and fails the build
+when a dependent pair comes closer than the distances below (counted in instructions; `s_nop n` counts n + 1).
+
+usage: check_asm_hazards.py file.s [kernel-name-substring]"""
+import re
+import sys
+
+# Distances (each one above what was measured / what hipcc itself pads for the builtin form of v_mfma_f32_16x16x32_bf16, a
+# 4-pass XDL op): VALU write -> MFMA read needs 2 wait states (an `s_nop 1` in front of every MFMA made a build with
+# compiler-inserted copies bit-exact again, `s_nop 0` did not); hipcc pads `s_nop 2` between such an MFMA and a write to
+# its srcC registers (A / B operands are read at issue: it pads nothing for those); XDL 4-pass result -> VALU read: 7.
+RAW_VALU_TO_MFMA = 3   # VALU (incl. v_accvgpr_write) writes a register an MFMA reads
+WAR_MFMA_SRCC = 4      # a VALU instruction writes a register an MFMA issued just before reads as srcC
+RAW_MFMA_TO_ANY = 8    # anything but an MFMA reads an MFMA result
+
+REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
+
+
+def regs(tok):
+    out = set()
+    for m in REG.finditer(tok):
+        lo = int(m.group(2) if m.group(2) is not None else m.group(3))
+        hi = int(m.group(2) if m.group(2) is not None else m.group(4))
+        out.update((m.group(1), i) for i in range(lo, hi + 1))
+    return out
+
+
+def parse(path, kernel):
+    ins, on = [], False
+    for line in open(path):
+        if re.match(r"^_Z\w*%s\w*:" % kernel, line):
+            on = True
+            continue
+        if not on:
+            continue
+        s = line.strip()
+        if s.startswith("s_endpgm"):
+            on = False
+            continue
+        if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
+            continue
+        mnem, _, rest = s.partition(" ")
+        ops = [o.strip() for o in rest.split(";")[0].split(",")] if rest else []
+        ins.append((mnem, ops, s))
+    return ins
+
+
+def defs_uses(mnem, ops):
+    """(written registers, read registers) of the instruction forms this kernel contains"""
+    if mnem.startswith(("v_mfma", "v_")) or mnem.startswith(("ds_read", "global_load", "buffer_load", "scratch_load")):
+        d = regs(ops[0]) if ops else set()
+        u = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+        return d, u
+    if mnem.startswith(("ds_write", "global_store", "buffer_store", "scratch_store", "global_atomic")):
+        return set(), set().union(*[regs(o) for o in ops]) if ops else set()
+    return set(), set().union(*[regs(o) for o in ops]) if ops else set()
+
+
+def check(path, kernel="mlp_bf16_fwd_kernel"):
+    ins = parse(path, kernel)
+    if not any(m.startswith("v_mfma") for m, _, _ in ins):
+        raise SystemExit("check_asm_hazards: no MFMA found in %s (kernel %s)" % (path, kernel))
+    du = [defs_uses(m, o) for m, o, _ in ins]
+    slots = [int(o[0]) + 1 if m == "s_nop" and o else 1 for m, o, _ in ins]
+    bad = []
+    for i, (m, o, text) in enumerate(ins):
+        if not m.startswith("v_mfma"):
+            continue
+        d_i, u_i = du[i]
+        # backwards: a VALU result read by this MFMA
+        dist, j = 0, i - 1
+        while j >= 0 and dist < RAW_VALU_TO_MFMA:
+            mj = ins[j][0]
+            if mj.startswith("v_") and not mj.startswith("v_mfma") and du[j][0] & u_i:
+                bad.append("VALU write -> MFMA read, %d apart:\n    %s\n    %s" % (dist + 1, ins[j][2], text))
+            dist += slots[j]
+            j -= 1
+        # forwards: writers of this MFMA's sources, readers of its result
+        dist, j = 0, i + 1
+        while j < len(ins) and dist < RAW_MFMA_TO_ANY:
+            mj = ins[j][0]
+            if not mj.startswith("v_mfma"):
+                # (LDS / VMEM loads into such a register return tens of cycles later: only VALU writes can land in time)
+                if dist < WAR_MFMA_SRCC and len(o) > 3 and mj.startswith("v_") and du[j][0] & regs(o[3]):
+                    bad.append("MFMA srcC read -> write, %d apart:\n    %s\n    %s" % (dist + 1, text, ins[j][2]))
+                if du[j][1] & d_i:
+                    bad.append("MFMA write -> read, %d apart:\n    %s\n    %s" % (dist + 1, text, ins[j][2]))
+            dist += slots[j]
+            j += 1
+    return len([1 for m, _, _ in ins if m.startswith("v_mfma")]), bad
+
+
+if __name__ == "__main__":
+    n, bad = check(sys.argv[1], *(sys.argv[2:3]))
+    for b in bad[:20]:
+        print(b)
+    print("check_asm_hazards: %d MFMAs, %d too-close dependent pairs" % (n, len(bad)))
+    sys.exit(1 if bad else 0)

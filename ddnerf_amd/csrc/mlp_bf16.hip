@@ -295,6 +295,36 @@ __device__ __forceinline__ const bf16x8 &bsrc(const Regs &r, int c) {
     else return r.HB[c][KS];
 }
 
+// One matrix instruction, written as asm so that the accumulator stays IN PLACE (vdst = srcC).  hipcc's own selection --
+// once a kernel uses the accumulator half of the register file at all -- is the untied form with an early-clobber
+// destination: the tile hops to fresh registers on every instruction, and each register it leaves behind costs wait
+// states when the next load or VALU result lands in it.  Nothing is padded inside asm (cdna_hip_programming.md 5.7), so
+// the schedule keeps every dependent pair far apart by construction: a tile is read by the VALU >= 3 MFMAs after its last
+// write, re-pack results are read by MFMAs at least a k-step later, same-tile MFMAs are 4 apart.
+// B_IN_A: the B operand lives in the accumulator half (HA, X) / in arch VGPRs (HB).  FIRST: start from the bias tile.
+#define BF16_STR2(x) #x
+#define BF16_STR(x) BF16_STR2(x)
+#ifdef BF16_MFMA_PAD  // debug build: wait states in front of every MFMA (or only the first of a block: BF16_PAD_FIRST_ONLY)
+#define MFMA_OP_PAD "s_nop " BF16_STR(BF16_MFMA_PAD) "\n\tv_mfma_f32_16x16x32_bf16"
+#else
+#define MFMA_OP_PAD "v_mfma_f32_16x16x32_bf16"
+#endif
+#ifdef BF16_PAD_FIRST_ONLY
+#define MFMA_OP "v_mfma_f32_16x16x32_bf16"
+#else
+#define MFMA_OP MFMA_OP_PAD
+#endif
+template <bool B_IN_A, bool FIRST>
+__device__ __forceinline__ void mfma(f32x4 &acc, const bf16x8 &a, const bf16x8 &b, const f32x4 &bias) {
+    if constexpr (FIRST) {
+        if constexpr (B_IN_A) asm volatile(MFMA_OP_PAD " %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(bias));
+        else asm volatile(MFMA_OP_PAD " %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(bias));
+    } else {
+        if constexpr (B_IN_A) asm volatile(MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+        else asm volatile(MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
+}
+
 // LDS byte address (relative to the ring base) of the A fragment of global k-step n (cyclic over tiles)
 __host__ __device__ constexpr int kstep_block(int n) {
     int gb = 0;
@@ -398,11 +428,16 @@ __device__ __forceinline__ void repack_step(Regs &r) {
                 w[2 * (b & 1)] = to_agpr_here(r.rp[C][0]);
                 w[2 * (b & 1) + 1] = to_agpr_here(r.rp[C][1]);
                 r.HA[C][b / 2] = __builtin_bit_cast(bf16x8, w);
+                // the fragment is complete: from here on it is ONE 128-bit value born in the accumulator half, which is
+                // what the MFMA asm asks for -- otherwise LLVM assembles some fragments in arch VGPRs and copies them
+                // over right in front of the MFMA, where nothing pads the VALU-write -> MFMA-read wait states
+                if constexpr ((b & 1) == 1) asm volatile("" : "+a"(r.HA[C][b / 2]));
             } else {
                 u32x4 w = __builtin_bit_cast(u32x4, r.HB[C][b / 2]);
                 w[2 * (b & 1)] = r.rp[C][0];
                 w[2 * (b & 1) + 1] = r.rp[C][1];
                 r.HB[C][b / 2] = __builtin_bit_cast(bf16x8, w);
+                if constexpr ((b & 1) == 1) asm volatile("" : "+v"(r.HB[C][b / 2]));
             }
         }
     }
@@ -416,7 +451,9 @@ __device__ __forceinline__ bf16x8 to_agpr8(bf16x8 v) {
     w[1] = to_agpr_here(w[1]);
     w[2] = to_agpr_here(w[2]);
     w[3] = to_agpr_here(w[3]);
-    return __builtin_bit_cast(bf16x8, w);
+    bf16x8 o = __builtin_bit_cast(bf16x8, w);
+    asm volatile("" : "+a"(o));
+    return o;
 }
 // event of block gb: 0 none, 1+q load group q, 5+q convert group q
 __host__ __device__ constexpr int x_event(int gb) {
@@ -455,10 +492,11 @@ __device__ __forceinline__ void block_compute(Regs &r, const Dma &d, const char 
         constexpr int ks = decltype(ksc)::value, n = K0 + ks;
         static_for<NCB>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            if constexpr (ks == 0)
-                r.acc[par][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.ring[n % BF16_DEPTH], bsrc<L, ks>(r, c), r.biasv[par], 0, 0, 0);
-            else
-                r.acc[par][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.ring[n % BF16_DEPTH], bsrc<L, ks>(r, c), r.acc[par][c], 0, 0, 0);
+            mfma<(L == 0 || (L == 5 && ks >= 8) || (L == 9 && ks >= 8) || (L & 1) == 1), ks == 0>(
+                r.acc[par][c], r.ring[n % BF16_DEPTH], bsrc<L, ks>(r, c), r.biasv[par]);
+            // the bias tile stays allocated until the MFMAs that read it as srcC are well under way (a dead register is
+            // re-used at once, and a VALU write within 3 wait states of such an MFMA corrupts its srcC read)
+            if constexpr (ks == 1 && c == 0) asm volatile("" ::"v"(r.biasv[par]));
             if constexpr (c == 0) {
                 // the slot of the PREVIOUS k-step's fragment is refilled (one MFMA behind its last reader: a load into a
                 // register that the MFMA just issued still reads costs wait states)
