@@ -377,10 +377,18 @@ __device__ __forceinline__ void dma_item(Regs &r, const Dma &d) {
     constexpr int q = wrapi(Q, NPWP), T = piece_stage(q);
     if constexpr (T >= 0) {
         constexpr int i = q - kPlan.s_p0[T];
+#if defined(BF16_NO_PARK)  // ablation builds (wrong results): loads only / parks only
+        if constexpr (PARK) asm volatile("" ::"v"(r.pf[q % BF16_PFD]));
+#else
         if constexpr (PARK) *(f32x4 *)(lds_ptr(r.pbase[T & 1]) + WG_WAVES * i * 1024) = r.pf[q % BF16_PFD];
+#endif
+#if defined(BF16_NO_LOAD)
+        else asm volatile("" : "+v"(r.pf[q % BF16_PFD]));
+#else
         else
             r.pf[q % BF16_PFD] = __builtin_bit_cast(
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rsrc, d.lane16, d.swave + (kPlan.s_goff[T] + WG_WAVES * i * 1024), 0));
+#endif
     }
 }
 
@@ -531,6 +539,16 @@ __device__ __forceinline__ void block_compute(Regs &r, const Dma &d, const char 
     }
 }
 
+#ifdef BF16_STAMP
+// Diagnostic build only (scratch/ab/build_bf16_variants.sh stamp; never in libddnerf_hip.so): the in-kernel clock,
+// MI355X_MICROARCH.md "DVFS give-back" item 6.  Every workgroup stamps s_memtime / s_memrealtime around its tile loop into a
+// buffer of its own (set through ddnerf_debug_set_stamps); no output value depends on a stamp.
+__device__ unsigned long long *g_bf16_stamps;
+DDN_EXPORT int ddnerf_debug_set_stamps(void *p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bf16_stamps), &p, sizeof(p));
+}
+#endif
+
 template <bool DEPTH_HEAD>
 __global__ __launch_bounds__(WG_THREADS, 1) void mlp_bf16_fwd_kernel(const char *__restrict__ feat,
                                                                      const char *__restrict__ packed,
@@ -583,6 +601,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void mlp_bf16_fwd_kernel(const char 
     read_bias<0>(r);
     __builtin_amdgcn_sched_barrier(0);
 
+#ifdef BF16_STAMP
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    const long st_first = tile;
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
         unsigned xoff[NCB];  // next tile's feature rows (clamped: the loads of a tile that does not exist are harmless)
 #pragma unroll
@@ -615,6 +637,19 @@ __global__ __launch_bounds__(WG_THREADS, 1) void mlp_bf16_fwd_kernel(const char 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef BF16_STAMP
+    {
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *sp = g_bf16_stamps;
+        if (sp && tid == 0) {
+            sp[5 * blockIdx.x + 0] = st_t0;
+            sp[5 * blockIdx.x + 1] = st_r0;
+            sp[5 * blockIdx.x + 2] = st_t1;
+            sp[5 * blockIdx.x + 3] = st_r1;
+            sp[5 * blockIdx.x + 4] = (unsigned long long)((tile - st_first) / gridDim.x);
+        }
+    }
+#endif
 }
 
 DDN_EXPORT int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M,

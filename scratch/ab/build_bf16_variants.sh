@@ -12,6 +12,7 @@ for v in "$@"; do
     norepack) build norepack -DBF16_NO_REPACK & ;;
     pfd8) build pfd8 -DBF16_PFD=8 & ;;
     pfd2) build pfd2 -DBF16_PFD=2 & ;;
+    stamp) build stamp -DBF16_STAMP & ;;
     v1) hipcc $FL scratch/ab/v1/mlp_bf16_32x32.hip $C/api.hip -o $O/bf16_v1.so 2> $O/bf16_v1.err || echo "FAILED v1" & ;;
     *) build "$v" $(echo "$v" | tr ',' ' ') & ;;
   esac

@@ -161,6 +161,68 @@ __global__ __launch_bounds__(256, 1) void loop_kernel(const bf16x8 *__restrict__
     if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
 }
 
+// 8 waves per workgroup (two per SIMD), 32 samples per wave: the same 256-sample tile, A fragments feed two MFMAs each,
+// every wave stages half as many pieces.  SRC as above (1: LDS reads, 2: + staging).
+template <int SRC>
+__global__ __launch_bounds__(512, 2) void loop_kernel8(const bf16x8 *__restrict__ data, float *__restrict__ out,
+                                                       Stamp *__restrict__ stamps, int iters, const char *__restrict__ wstream) {
+    __shared__ __attribute__((aligned(16))) char lds[NSLICE * 32 * ROWB1 + 16384];
+    constexpr int ROWB = ROWB1;
+    char *stage_dst = lds + NSLICE * 32 * ROWB1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (int)sizeof(lds) / 16; i += 512) ((bf16x8 *)lds)[i] = data[(i * 7 + blockIdx.x) & 4095];
+    bf16x8 B[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) B[i] = data[(tid * 16 + i + blockIdx.x * 17) & 4095];
+    f32x4 pf[2];
+    if constexpr (SRC == 2)
+        for (int i = 0; i < 2; ++i) pf[i] = *(const f32x4 *)(wstream + (wave * 2 + i) * 1024 + lane * 16);
+    __syncthreads();
+    f32x4 acc16[4] = {};
+    unsigned long long t0 = 0, r0 = 0;
+    if (stamps) {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int it = 0; it < iters; ++it) {
+        const int sl = it & (NSLICE - 1);
+        const char *wsrc = wstream + ((size_t)((it * 16 + wave * 2) & 1279) << 10) + lane * 16;
+        const char *a_lane = lds + sl * 32 * ROWB + (lane & 15) * ROWB + 16 * (lane >> 4);
+        bf16x8 ring[4][2];
+        static_for<4>([&](auto p) {
+            ring[p][0] = *(const bf16x8 *)(a_lane + 64 * p);
+            ring[p][1] = *(const bf16x8 *)(a_lane + 16 * ROWB + 64 * p);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<8>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            static_for<2>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const bf16x8 a = ring[p % 4][r];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc16[2 * r + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, B[2 * p + c], acc16[2 * r + c], 0, 0, 0);
+                if constexpr (p + 4 < 8) ring[p % 4][r] = *(const bf16x8 *)(a_lane + r * 16 * ROWB + 64 * (p + 4));
+                if constexpr (SRC == 2 && r == 0 && p % 4 == 0) {
+                    *(f32x4 *)(stage_dst + wave * 2048 + (p / 4) * 1024 + lane * 16) = pf[p / 4];
+                    pf[p / 4] = *(const f32x4 *)(wsrc + (p / 4) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    }
+    if (stamps) {
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) stamps[blockIdx.x] = Stamp{t0, r0, t1, r1};
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc16[i][0] + acc16[i][1] + acc16[i][2] + acc16[i][3];
+    s += ((const float *)stage_dst)[tid];
+    if (s == 12345.678f) out[blockIdx.x * 512 + tid] = s;
+}
+
 #define CK(x)                                                                  \
     do {                                                                       \
         hipError_t e = (x);                                                    \
@@ -215,6 +277,45 @@ static void run(const char *name, const char *wstream, const bf16x8 *data, float
     fflush(stdout);
 }
 
+template <int SRC>
+static void run8(const char *name, const char *wstream, const bf16x8 *data, float *out, Stamp *stamps, int iters, int grid, bool zeros) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int round = 0; round < 200 && ms < 2500.f; ++round) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((loop_kernel8<SRC>), dim3(grid), dim3(512), 0, 0, data, out, (Stamp *)nullptr, iters, wstream);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float t;
+        CK(hipEventElapsedTime(&t, e0, e1));
+        ms += t;
+    }
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((loop_kernel8<SRC>), dim3(grid), dim3(512), 0, 0, data, out, (Stamp *)nullptr, iters, wstream);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    t /= 20;
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((loop_kernel8<SRC>), dim3(grid), dim3(512), 0, 0, data, out, stamps, iters, wstream);
+    CK(hipDeviceSynchronize());
+    std::vector<Stamp> h(grid);
+    CK(hipMemcpy(h.data(), stamps, grid * sizeof(Stamp), hipMemcpyDeviceToHost));
+    std::vector<double> clk, cyc;
+    for (auto &s : h) {
+        clk.push_back((double)(s.t1 - s.t0) / (double)(s.r1 - s.r0) * 100.0);
+        cyc.push_back((double)(s.t1 - s.t0));
+    }
+    std::sort(clk.begin(), clk.end());
+    std::sort(cyc.begin(), cyc.end());
+    double flop = 2.0 * 32 * 32 * 256 * (double)iters * 8 * grid;  // per iteration per wave: 32 rows x 32 samples x 256 k
+    printf("%-38s %s  %.4f ms  %7.1f TFLOP/s  frac %.3f | in-kernel clock median %.0f MHz | %.1f cycles per wave iteration (two waves share a SIMD: ideal 1024)\n",
+           name, zeros ? "zeros " : "random", t, flop / t / 1e9, flop / t / 1e9 / 2500.0, clk[grid / 2], cyc[grid / 2] / iters);
+    fflush(stdout);
+}
+
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 2048;
     int grid = argc > 2 ? atoi(argv[2]) : 2048;
@@ -253,6 +354,8 @@ int main(int argc, char **argv) {
         run<1, 3>("16x16x32 LDS + staging LDS-DMA", ws, data, out, stamps, iters, grid, zeros);
         run<0, 4>("32x32x16 LDS + VGPR staging + repack", ws, data, out, stamps, iters, grid, zeros);
         run<1, 4>("16x16x32 LDS + VGPR staging + repack", ws, data, out, stamps, iters, grid, zeros);
+        run8<1>("16x16x32 8 waves x 32 smp, LDS", ws, data, out, stamps, iters, grid, zeros);
+        run8<2>("16x16x32 8 waves x 32 smp, LDS+staging", ws, data, out, stamps, iters, grid, zeros);
         run<0, 0>("32x32x16 A in registers (again)", ws, data, out, stamps, iters, grid, zeros);
     }
     return 0;
