@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the DDNeRF ray-march hot path on MI355X (contract: see the task's bench.py section).
 
-A "step" is one pass of the hot path over one batch of synthetic rays: `model.run_iter(...)` of the HIP-backed
-`DDNerfModel` at BASELINE.json configs[1] -- config_blender.yml, 4096 rays x (64 coarse + 128 fine) samples,
-8x256 MLPs, fp32 -- per GPU (weak scaling: every rank renders its own 4096-ray batch, no data-path collective
-in render mode; train mode adds the RCCL gradient all-reduce).  Inputs are resident in HBM before the timed region.
+A "step" is one pass of the hot path over one batch of synthetic rays: `model.run_iter(...)` of the HIP-backed model of
+`--config` (default BASELINE.json configs[1]: config_blender.yml, DDNerfModel, 4096 rays x (64 coarse + 128 fine) samples,
+8x256 MLPs, fp32) per GPU.  Weak scaling: every rank renders its own ray batch, no data-path collective in render mode;
+the train pass adds ONE RCCL all-reduce of the flat gradient buffer per network per step.  Inputs are resident in HBM
+before the timed region.
 
-Prints ONE JSON line on rank 0 with the metric, a `roofline` object for the dominant kernel (the fused fine-MLP
-forward: algorithmic FLOP per launch / mean launch duration measured with HIP events on the launch stream) and,
-at N=1, a `cpu_baseline` object (the CPU oracle timed on a bounded sample of the same workload) and a `bf16_tier`
-object and an `x3_tier` object (the same workload on the plain-bf16 and on the split-precision bf16x3 MLP kernels, each with
-its own roofline fraction against the bf16 MFMA peak), and a `train_tier` object (training steps per second of the same
-workload on the fp32 and the x3 kernels).
+`python bench.py --gpus N ...` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child process
+per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) before anything touches the GPU, and
+relays rank 0's line; under a launcher (torch.distributed.run) it checks that WORLD_SIZE == --gpus.
+
+Prints ONE JSON line on rank 0: the metric (render rays/s, whole job), a `roofline` object for the dominant kernel (the
+fused fine-MLP forward: algorithmic FLOP per launch / mean launch duration measured with HIP events on the launch stream)
+and
+  * at N = 1 (default run): `cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload), `x3_tier` /
+    `bf16_tier` (the same workload on the split-precision bf16x3 and on the plain bf16 MLP kernels, each with its own roofline
+    fraction against the bf16 MFMA peak) and `train_tier` (training steps of the same workload);
+  * at N > 1: `train` (forward + backward + gradient all-reduce + Adam of the same per-GPU batch, timed the same way),
+    `rccl_ranks` and `backend`.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,47 +32,106 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 FLOP_FINE = 1220608       # per sample, MipNeRFModel forward
 FLOP_COARSE_DD = 1221120  # per sample, DepthMipNeRFModel forward
 PEAK = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 DTYPE = {"fp32": "f32", "bf16": "bf16 (f32 accumulate)", "x3": "f32 as exact hi+lo bf16 splits, 3 bf16 MFMAs per product (f32 accumulate)"}
+TRAIN_DTYPE = {"fp32": "f32 forward / backward-data, weight gradients as bf16 hi+lo splits (3 MFMAs per product, f32 accumulate)",
+               "x3": DTYPE["x3"]}
+# BASELINE.json configs -> (synthetic ray kind, default MLP kernel, default rays per GPU)
+CONFIGS = {
+    "config_blender.yml": ("blender", "fp32", 4096),          # configs[1] (and [0] at 256 rays)
+    "config_ff.yml": ("llff", "bf16", 4096),                  # configs[2]: NDC rays, bf16-MFMA MLP
+    "config_360.yml": ("real360", "fp32", 8192),              # configs[3]: 8192 rays, data-parallel training
+    "config_blender_mipnerf.yml": ("blender", "fp32", 4096),  # configs[4]: GeneralMipNerfModel, one shared MLP
+    "config_ff_mipnerf.yml": ("llff", "fp32", 4096),
+    "config_360_mipnerf.yml": ("real360", "fp32", 8192),
+}
+KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_common.h"],
+                  "x3": ["mlp_x3.hip", "mlp_x3_common.h", "mlp_bf16_common.h"]}
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    p.add_argument("--config", default="config_blender.yml", choices=sorted(CONFIGS), help="configs/<name> (BASELINE.json configs)")
+    p.add_argument("--rays", type=int, default=None, help="rays per GPU per step (default: the config's BASELINE size)")
+    p.add_argument("--global-rays", type=int, default=None, help="strong scaling: this many rays per step split over the ranks")
     p.add_argument("--coarse", type=int, default=64)
     p.add_argument("--fine", type=int, default=128)
-    p.add_argument("--mode", choices=["render", "train"], default="render")
-    p.add_argument("--mlp", choices=["fp32", "x3", "bf16"], default="fp32")
+    p.add_argument("--mode", choices=["render", "train", "both"], default=None, help="default: render at N = 1, both at N > 1")
+    p.add_argument("--mlp", choices=["fp32", "x3", "bf16"], default=None, help="default: the config's BASELINE numerical mode")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-bf16-tier", action="store_true", help="skip the extra x3 / bf16 kernel measurements of the default run")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays of the same workload timed on the CPU oracle")
-    return p.parse_args()
+    args = p.parse_args(argv)
+    kind, mlp, rays = CONFIGS[args.config]
+    args.ray_kind = kind
+    args.mlp = args.mlp or mlp
+    args.mode = args.mode or ("render" if args.gpus == 1 else "both")
+    args.scaling = "strong" if args.global_rays else "weak"
+    if args.global_rays:
+        if args.global_rays % args.gpus:
+            p.error("--global-rays must be a multiple of --gpus")
+        args.rays = args.global_rays // args.gpus
+    args.rays = args.rays or rays
+    return args
+
+
+def rank_environments(n, port):
+    """The environment of each of the N ranks the launcher starts (what torch.distributed.run would set, one node)."""
+    return [dict(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0") for r in range(n)]
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start the N ranks as child processes, one per GPU (nothing in this process has touched
+    the GPU), relay rank 0's single JSON line and exit with the first non-zero exit code."""
+    import torch
+
+    have = torch.cuda.device_count()  # (does not initialise the GPU)
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
+    port = 29400 + os.getpid() % 2000
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r, env in enumerate(rank_environments(args.gpus, port)):
+        procs.append(subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    if any(codes) or len(lines) != 1:
+        sys.stderr.write(out[-4000:])
+        raise SystemExit("bench.py --gpus %d: rank exit codes %s, %d result lines" % (args.gpus, codes, len(lines)))
+    print(lines[0], flush=True)
+    raise SystemExit(0)
 
 
 def build_model(args, device, mlp=None):
+    import torch
+
     from ddnerf_amd import synthetic
     from ddnerf_amd.cfgnode import CfgNode
     from models import models
 
-    cfg = CfgNode.load(os.path.join(ROOT, "configs", "config_blender.yml"))
+    cfg = CfgNode.load(os.path.join(ROOT, "configs", args.config))
     for mode in ("train", "validation"):
         cfg.nerf[mode]["num_coarse"] = args.coarse
         cfg.nerf[mode]["num_fine"] = args.fine
     cfg.nerf["mlp_dtype"] = mlp or args.mlp
     cfg.train_params.dist_reg_coeficient = min(max(1 / args.coarse, 0.01), 0.12)  # train_model.py:124-125
+    if cfg.dataset.get("normalize_poses", False):  # data_utils/data_utils.py:65-74 rescales near/far with the poses
+        cfg.dataset.near = cfg.dataset.near / cfg.dataset.normalize_factor
+        cfg.dataset.far = cfg.dataset.far / cfg.dataset.normalize_factor
     model = getattr(models, cfg.nerf.type)(cfg)
-    sd_c = synthetic.make_state_dict(True, 11, 20.0)   # weight set B ("sharpened"), SURVEY.md 8d
+    dd = cfg.nerf.type == "DDNerfModel"
+    sd_c = synthetic.make_state_dict(dd, 11, 20.0)   # weight set B ("sharpened"), SURVEY.md 8d
     sd_f = synthetic.make_state_dict(False, 12, 20.0)
     model.coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
-    model.fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    if model.fine is not model.coarse:
+        model.fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
     model.to(device)
     return model, cfg, sd_c, sd_f
 
@@ -76,6 +144,8 @@ class KernelTimer:
         self.active = False
 
     def __call__(self, M, launch):
+        import torch
+
         if not self.active:
             return launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -90,19 +160,21 @@ class KernelTimer:
         return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
 
 
+def child_line(args, extra):
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--rays", str(args.rays), "--coarse", str(args.coarse),
+           "--fine", str(args.fine), "--no-cpu-baseline", "--no-bf16-tier"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
 def train_tier(args, mlp):
     """Training throughput (forward + backward + Adam per step) of the same workload, from a child run of
     `bench.py --mode train --mlp <mlp>`; reported beside the render headline, never as `value`."""
-    import subprocess
-
-    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--mlp", mlp, "--steps", "5", "--warmup", "2",
-           "--rays", str(args.rays), "--coarse", str(args.coarse), "--fine", str(args.fine), "--no-cpu-baseline"]
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        d = json.loads(out.stdout.strip().splitlines()[-1])
+        d = child_line(args, ["--mode", "train", "--mlp", mlp, "--steps", "5", "--warmup", "2"])
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
-    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"]}
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "roofline": d.get("roofline")}
 
 
 def extra_tier(args, mlp):
@@ -112,25 +184,21 @@ def extra_tier(args, mlp):
     meets the same 1e-4 parity bar as the exact kernel) -- its roofline counts the 3x bf16 MFMA work it really issues.
     Measured by a child `bench.py --mlp <tier>` run so that it sees a fresh allocator / launch-path state (inside this
     process, behind the fp32 run, the CPU-launch-bound bf16 step measures up to 4x slower)."""
-    import subprocess
-
-    cmd = [sys.executable, os.path.abspath(__file__), "--mlp", mlp, "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--rays", str(args.rays), "--coarse", str(args.coarse), "--fine", str(args.fine), "--no-cpu-baseline",
-           "--no-bf16-tier"]
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        d = json.loads(out.stdout.strip().splitlines()[-1])
+        d = child_line(args, ["--mlp", mlp, "--steps", str(args.steps), "--warmup", str(args.warmup)])
     except Exception as e:  # the headline must not die with a tier
         return {"error": "%s: %s" % (type(e).__name__, e)}
     roof = d["roofline"]
     if roof:
-        roof.pop("traffic", None)
         roof["fp32_equivalent_tflops"] = round(roof["achieved"] / (3 if mlp == "x3" else 1), 2)
     return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "roofline": roof}
 
 
 def cpu_baseline(args, cfg, sd_c, sd_f):
     """The CPU oracle (a C port of the reference path, oracle/) on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+
     import oracle as O
     from ddnerf_amd import synthetic
 
@@ -159,99 +227,164 @@ def cpu_baseline(args, cfg, sd_c, sd_f):
             "sample": "%d rays x (%d+%d) samples, render pass, C oracle with OpenMP, %.1f s" % (n, args.coarse, args.fine, dt)}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def kernel_source_digest(mlp):
+    h = hashlib.md5()
+    for f in KERNEL_SOURCES[mlp]:
+        h.update(open(os.path.join(ROOT, "ddnerf_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def measured_traffic(args):
+    """HBM bytes per launch of the fine-MLP kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/r02_hbm_traffic_<mlp>.json).  Only quoted when that profile was taken on THIS kernel source (digest recorded
+    in the file) and at this launch size; otherwise null."""
+    tf = os.path.join(ROOT, "profiles", "r02_hbm_traffic_%s.json" % args.mlp)
+    if not (os.path.exists(tf) and (args.rays, args.fine) == (4096, 128)):
+        return None, None
+    d = json.load(open(tf))
+    if d.get("kernel_source_md5") != kernel_source_digest(args.mlp):
+        return None, None
+    return d.get("fine_mlp_%s_fwd_hbm_bytes_per_launch" % args.mlp), os.path.relpath(tf, ROOT)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        launch_ranks(args, argv)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N` or under a launcher "
+                         "with --nproc-per-node N)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    backend = None
     if dist:
         import torch.distributed as td
 
-        td.init_process_group("nccl", device_id=device)
+        td.init_process_group("nccl", device_id=device)  # "nccl" IS RCCL on ROCm
+        backend = "%s (RCCL)" % td.get_backend()
     from ddnerf_amd import ops, synthetic
 
     model, cfg, sd_c, sd_f = build_model(args, device)
-    ro, rd, rad, tgt = (torch.from_numpy(x).to(device) for x in synthetic.make_rays("blender", args.rays, 1 + rank))
+    ro, rd, rad, tgt = (torch.from_numpy(x).to(device) for x in synthetic.make_rays(args.ray_kind, args.rays, 1 + rank))
     torch.manual_seed(1234 + rank)
 
     timer = KernelTimer()
     ops.MLP_LAUNCH_HOOK = timer
-
-    if args.mode == "render":
-        model.eval()
-
-        def step():
-            with torch.no_grad():
-                return model.run_iter(ro, rd, rad, mode="validation", rgb_target=tgt)
-    else:
-        from ddnerf_amd import train_step
-
-        stepper = train_step.TrainStepper(model, cfg, dist=dist)
-
-        def step():
-            return stepper.step(ro, rd, rad, tgt)
 
     def fence():
         if dist:
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    timer.active = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    timer.active = False
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(step):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize fences; max over ranks."""
+        for _ in range(args.warmup):
+            step()
+        fence()
+        timer.pairs.clear()
+        timer.active = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        timer.active = False
+        if dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    M_fine = args.rays * args.fine
+    res = {}
+    if args.mode in ("render", "both"):
+        model.eval()
+
+        def render_step():
+            with torch.no_grad():
+                return model.run_iter(ro, rd, rad, mode="validation", rgb_target=tgt)
+
+        res["render"] = (timed(render_step), timer.mean_ms(M_fine))
+    if args.mode in ("train", "both"):
+        if args.mlp == "bf16":
+            raise SystemExit("bench.py: training runs on the fp32 / x3 MLP kernels (--mlp fp32|x3)")
+        from ddnerf_amd import train_step
+
+        stepper = train_step.TrainStepper(model, cfg, dist=dist)
+        res["train"] = (timed(lambda: stepper.step(ro, rd, rad, tgt)), timer.mean_ms(M_fine))
 
     if rank == 0:
-        M_fine = args.rays * args.fine
-        ms, launches = timer.mean_ms(M_fine)
+        head = "render" if "render" in res else "train"
+        dt, (ms, launches) = res[head]
         roof = None
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s.json" % args.mlp)
-        if os.path.exists(tf) and args.mode == "render" and (args.rays, args.fine) == (4096, 128):
-            # HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (see the file)
-            traffic = json.load(open(tf)).get("fine_mlp_%s_fwd_hbm_bytes_per_launch" % args.mlp)
-        if ms:
+        if ms and head == "render":
+            traffic, src = measured_traffic(args)
             ach = (3 if args.mlp == "x3" else 1) * M_fine * FLOP_FINE / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "mlp_%s_fwd_kernel<fine> (%d samples/launch)" % (args.mlp, M_fine),
                     "achieved": round(ach, 2), "peak": PEAK[args.mlp], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK[args.mlp], 4), "traffic": traffic, "launch_ms": round(ms, 4),
-                    "launches_timed": launches}
+                    "frac": round(ach / PEAK[args.mlp], 4), "traffic": traffic, "traffic_source": src,
+                    "launch_ms": round(ms, 4), "launches_timed": launches}
+        elif head == "train":
+            roof = train_roofline(args, cfg, dt / args.steps)
+        net = "DDNerfModel" if cfg.nerf.type == "DDNerfModel" else "GeneralMipNerfModel (one shared MLP)"
         line = {
             "metric": "rays/sec (4096 rays x 128 samples, 8x256 MLP)",
             "value": round(world * args.rays * args.steps / dt, 1), "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE[args.mlp], "data": "synthetic",
-            "config": {"workload": "config_blender.yml DDNerfModel, %d rays/GPU x (%d coarse + %d fine), run_iter %s pass"
-                                   % (args.rays, args.coarse, args.fine, args.mode),
-                       "rays_per_gpu": args.rays, "mode": args.mode, "weights": "seeded, fc_alpha x20",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": DTYPE[args.mlp] if head == "render" else TRAIN_DTYPE[args.mlp], "data": "synthetic",
+            "config": {"workload": "%s %s, %d rays/GPU x (%d coarse + %d fine), %s rays, run_iter %s pass"
+                                   % (args.config, net, args.rays, args.coarse, args.fine, args.ray_kind, head),
+                       "rays_per_gpu": args.rays, "global_rays": world * args.rays, "mode": head, "weights": "seeded, fc_alpha x20",
                        "parallelism": "dp%d (independent ray batches)" % world},
             "roofline": roof,
         }
-        if world == 1 and args.mode == "render" and args.mlp == "fp32" and not args.no_bf16_tier:
+        if dist:
+            line["rccl_ranks"] = td.get_world_size()
+            line["backend"] = backend
+        if head == "render" and "train" in res:
+            tdt = res["train"][0]
+            line["train"] = {"value": round(world * args.rays * args.steps / tdt, 1), "unit": "rays/s",
+                             "ms_per_step": round(tdt / args.steps * 1e3, 4), "dtype": TRAIN_DTYPE[args.mlp],
+                             "collective": "one all-reduce of the flat fp32 gradient buffer per network per step" if dist else None,
+                             "roofline": train_roofline(args, cfg, tdt / args.steps)}
+        if world == 1 and args.mode == "render" and args.mlp == "fp32" and args.config == "config_blender.yml" and not args.no_bf16_tier:
             line["x3_tier"] = extra_tier(args, "x3")
             line["bf16_tier"] = extra_tier(args, "bf16")
             line["train_tier"] = {"fp32": train_tier(args, "fp32"), "x3": train_tier(args, "x3")}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "config_blender.yml":
             line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f)
         print(json.dumps(line), flush=True)
     if dist:
         td.destroy_process_group()
+
+
+def train_roofline(args, cfg, step_s):
+    """Whole-step MFMA roofline of a training step: algorithmic FLOP of the forward, the backward-data pass (no input
+    gradient for the first layer and the feature columns) and the weight gradients of both networks / step time."""
+    dd = cfg.nerf.type == "DDNerfModel"
+    m_c, m_f = args.rays * args.coarse, args.rays * args.fine
+    f_c, f_f = (FLOP_COARSE_DD if dd else FLOP_FINE), FLOP_FINE
+    first = 2 * (96 * 256 + 96 * 256 + 27 * 128)  # products that need no input gradient: layer 0, the skip's xyz and the dir columns
+    flop = m_c * (3 * f_c - first) + m_f * (3 * f_f - first)
+    issued = 3 if args.mlp == "x3" else 1
+    peak = PEAK["x3"] if args.mlp == "x3" else PEAK["fp32"]
+    ach = issued * flop / step_s / 1e12
+    return {"bound": "mfma", "kernel": "whole training step (forward + backward-data + weight gradients of both networks)",
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "algorithmic_flop_per_step": flop, "note": "x3: three bf16 MFMAs issued per product" if args.mlp == "x3" else
+            "fp32 MFMA for forward / backward-data; weight gradients run on the bf16 cores (x3) and are counted once"}
 
 
 if __name__ == "__main__":

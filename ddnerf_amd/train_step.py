@@ -10,7 +10,7 @@ from . import schedules
 
 
 class TrainStepper:
-    def __init__(self, model, cfg, dist=False, optimizers=None):
+    def __init__(self, model, cfg, dist=False, optimizers=None, single_rank_collectives=False):
         self.model, self.cfg = model, cfg
         self.dd = cfg.nerf.type == "DDNerfModel"
         if optimizers is None:  # train_model.py:84-98: one optimiser per network, lr set per step
@@ -20,7 +20,7 @@ class TrainStepper:
                 optimizers.append(opt(model.fine.parameters(), lr=cfg.optimizer.lr))
         self.optims = optimizers
         self.smooth = schedules.SmoothingSchedule(cfg)
-        self.buckets = ddp.GradBuckets([model.fine, model.coarse]) if dist else None
+        self.buckets = ddp.GradBuckets([model.fine, model.coarse], single_rank_collectives=single_rank_collectives) if dist else None
         if dist:
             ddp.broadcast_parameters([model.coarse, model.fine])
         self.iter = 0

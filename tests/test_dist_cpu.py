@@ -1,6 +1,7 @@
 """world_size-2 gloo tests (CPU, no kernels) of the data-parallel gradient buckets: every rank ends with the
-world-average gradient, for the aliased-flat-buffer fast path, the early (in-backward) launch and the gathered
-fallback; parameters are broadcast from rank 0."""
+world-average gradient, for the aliased-flat-buffer fast path, the early (in-backward) launch, the gathered
+fallback, pre-existing .grad tensors (no early launch: autograd would accumulate into the buffer being reduced) and
+gradient accumulation (loud failure with early launches, correct sums without); parameters are broadcast from rank 0."""
 import os
 
 import pytest
@@ -21,31 +22,67 @@ def _worker(rank, world, port, mode, q):
         coarse = BA.DepthMipNeRFModel(hidden_size=256, include_input_dir=True)
         ddp.broadcast_parameters([coarse, fine])
         w_sum = float(fine.flat_params().double().sum()) + float(coarse.flat_params().double().sum())
-        buckets = ddp.GradBuckets([fine, coarse, fine])   # duplicates collapse
+        buckets = ddp.GradBuckets([fine, coarse, fine], early=(mode != "accumulate_deferred"))   # duplicates collapse
         assert len(buckets.nets) == 2 and buckets.world == world
+        scale = 1.0
+
+        def views_of(net, flat):
+            off, out = 0, []
+            for p in net.parameters():
+                out.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            return out
+
         for net in (fine, coarse):
             n = sum(p.numel() for p in net.parameters())
             flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
-            if mode in ("aliased", "early"):
-                off = 0
+            net.last_flat_grad = flat
+            if mode == "aliased":          # .grad = views of the flat buffer, reduced in finish()
+                for p, v in zip(net.parameters(), views_of(net, flat)):
+                    p.grad = v
+            elif mode == "early":          # what the fused backward does: bucket ready while every .grad is None -> launch
+                net._fwd_calls = 1
+                buckets.on_flat_grad_ready(net, flat)
+                for p, v in zip(net.parameters(), views_of(net, flat)):   # autograd steals the views
+                    p.grad = v
+            elif mode == "preexisting":    # .grad tensors exist (zero_grad(set_to_none=False)): autograd would ACCUMULATE
                 for p in net.parameters():
-                    p.grad = flat[off:off + p.numel()].view(p.shape)
-                    off += p.numel()
-                net.last_flat_grad = flat
-                if mode == "early":
-                    net._fwd_calls = 1
-                    buckets.on_flat_grad_ready(net, flat)
+                    p.grad = torch.zeros_like(p)
+                net._fwd_calls = 1
+                buckets.on_flat_grad_ready(net, flat)        # must not launch: the accumulation reads `flat`
+                for p, v in zip(net.parameters(), views_of(net, flat)):
+                    p.grad += v
+            elif mode in ("accumulate", "accumulate_deferred"):   # two backward passes before finish()
+                net._fwd_calls = 1
+                buckets.on_flat_grad_ready(net, flat)
+                for p, v in zip(net.parameters(), views_of(net, flat)):
+                    p.grad = v
+                net._fwd_calls = 2
+                buckets.on_flat_grad_ready(net, flat)
+                for p in net.parameters():
+                    p.grad += p.grad.clone() * 0 + 1.0        # a second, un-reduced contribution (1.0 everywhere)
             else:  # gathered: independent .grad tensors, no flat buffer
-                off = 0
-                for p in net.parameters():
-                    p.grad = flat[off:off + p.numel()].view(p.shape).clone()
-                    off += p.numel()
+                for p, v in zip(net.parameters(), views_of(net, flat)):
+                    p.grad = v.clone()
+        if mode == "early":
+            assert buckets.early_launches == 2
+        if mode in ("preexisting", "accumulate_deferred"):
+            assert buckets.early_launches == 0
+        if mode == "accumulate":            # reduced + un-reduced gradients in one buffer: must fail loudly, not average wrongly
+            try:
+                buckets.finish()
+                ok = False
+            except RuntimeError:
+                ok = True
+            q.put((rank, ok, w_sum))
+            return
         buckets.finish()
         ok = True
+        extra = 1.0 if mode == "accumulate_deferred" else 0.0
         for net in (fine, coarse):
             off = 0
             for p in net.parameters():
-                exp = torch.arange(off, off + p.numel(), dtype=torch.float32).view(p.shape) * (sum(range(1, world + 1)) / world)
+                exp = torch.arange(off, off + p.numel(), dtype=torch.float32).view(p.shape) * (sum(range(1, world + 1)) / world) + extra
                 ok &= bool(torch.allclose(p.grad, exp, rtol=1e-6, atol=0))
                 off += p.numel()
             ok &= net._fwd_calls == 0
@@ -54,7 +91,7 @@ def _worker(rank, world, port, mode, q):
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["aliased", "early", "gathered"])
+@pytest.mark.parametrize("mode", ["aliased", "early", "gathered", "preexisting", "accumulate", "accumulate_deferred"])
 def test_grad_buckets_world2_gloo(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -92,3 +92,59 @@ def test_data_parallel_training_two_ranks_one_gpu(mlp_dtype):
         p.join(60)
         assert p.exitcode == 0
     assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res), res
+
+
+def _rccl_worker(port, q):
+    """ONE rank over backend "nccl" (= RCCL): the code path of a multi-GPU run -- process-group init with a device id, the
+    flat-parameter broadcast, the in-backward async all-reduce on RCCL's stream and Work.wait() -- on the one GPU of the box."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import sys
+        sys.path.insert(0, ROOT)
+        from ddnerf_amd import dist as ddp, synthetic, train_step
+        from ddnerf_amd.cfgnode import CfgNode
+        from models import models
+
+        def make():
+            cfg = CfgNode.load(os.path.join(ROOT, "configs", "config_ff.yml"))
+            for mode in ("train", "validation"):
+                cfg.nerf[mode].update(num_coarse=16, num_fine=16, perturb=False, radiance_field_noise_std=0.0)
+            cfg.nerf["mlp_dtype"] = "x3"
+            cfg["scheduler"] = {"lr_init": 1e-3, "lr_final": 1e-3, "lr_delay_steps": 0}
+            model = getattr(models, cfg.nerf.type)(cfg)
+            for net, dd, seed in ((model.coarse, True, 11), (model.fine, False, 12)):
+                net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(dd, seed, 4.0).items()})
+            model.to("cuda")
+            return model, cfg
+
+        rays = tuple(torch.from_numpy(x).cuda() for x in synthetic.make_rays("llff", 64, 31))
+        # plain single-process training: no reducer at all
+        m0, c0 = make()
+        s0 = train_step.TrainStepper(m0, c0, dist=False)
+        # the same through RCCL collectives (one-rank group: sums are identities)
+        m1, c1 = make()
+        s1 = train_step.TrainStepper(m1, c1, dist=True, single_rank_collectives=True)
+        ok = td.get_backend() == "nccl" and s1.buckets.collect
+        for _ in range(2):
+            l0, _, _ = s0.step(*rays)
+            l1, _, _ = s1.step(*rays)
+        torch.cuda.synchronize()
+        ok &= s1.buckets.early_launches >= 2          # the fine bucket went out from inside the backward pass, every step
+        for a, b in ((m0.coarse, m1.coarse), (m0.fine, m1.fine)):
+            ok &= bool(torch.equal(a.flat_params(), b.flat_params()))
+        ok &= bool(torch.equal(l0, l1))
+        q.put(bool(ok))
+    finally:
+        td.destroy_process_group()
+
+
+def test_rccl_code_path_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29850 + os.getpid() % 100, q))
+    p.start()
+    ok = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0 and ok
