@@ -36,8 +36,27 @@ def load_runiter(name):
         u_det=torch.linspace(0.0, 0.9999 if dd else 1.0, int(nf) + 1).numpy(),
         sd_coarse=synthetic.make_state_dict(dd, 11, sharpen),
         sd_fine=synthetic.make_state_dict(False, 12, sharpen) if dd else None,
+        dp_coef=float(g["dp_coef"]) if "dp_coef" in g else None,
     )
     return case
+
+
+def fullsize_names():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "fullsize_*.npz")))
+
+
+def load_fullsize(name):
+    """BASELINE-size validation fixtures (tests/golden/make_golden.py gen_fullsize): every `stride`-th ray's outputs of the
+    reference; rays and weights come from the synthetic seeds."""
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    _, tag, mt, kind, n, _ = name.split("_")
+    n_, nc, nf, sharpen, stride, near, far, dist_reg, smooth, pad = g["meta"]
+    assert int(n_) == int(n)
+    dd = mt == "dd"
+    return dict(g=g, tag=tag, dd=dd, kind=kind, n=int(n), nc=int(nc), nf=int(nf), stride=int(stride), near=float(near), far=float(far),
+                dist_reg=float(dist_reg), smooth=float(smooth), pdf_padding=bool(pad), noise=0.0, train=False, mode="validation",
+                sd_coarse=synthetic.make_state_dict(dd, 11, float(sharpen)),
+                sd_fine=synthetic.make_state_dict(False, 12, float(sharpen)) if dd else None, dp_coef=None)
 
 
 def maxerr(a, b):

@@ -330,7 +330,11 @@ def replay_randoms(seed, shapes):
 
 
 def gen_runiter():
-    for model_type, kind, n, nc, nf, sharpen, noise in (
+    for model_type, kind, n, nc, nf, sharpen, noise, *opt in (
+        # N = 64 gradient fixture with the dp-loss term switched off: the coarse net then receives ONLY the MSE
+        # gradient through composite_bwd -> MLP backward, which pins that chain tightly (the dp-loss gradient is ill-conditioned
+        # in the reference itself)
+        ("DDNerfModel", "blender", 64, 64, 64, 8.0, 0.0, "dp0"),
         ("DDNerfModel", "blender", 32, 64, 128, 20.0, 1.0),
         ("DDNerfModel", "blender", 24, 32, 32, 1.0, 0.0),
         ("DDNerfModel", "llff", 24, 16, 16, 20.0, 1.0),
@@ -340,6 +344,9 @@ def gen_runiter():
     ):
         cfgname = (CFG_OF if model_type == "DDNerfModel" else CFG_MIP_OF)[kind]
         cfg = load_cfg(cfgname, nc, nf, kind)
+        dp0 = "dp0" in opt
+        if dp0:
+            cfg.train_params.dp_coeficient = 0.0
         for mode in ("train", "validation"):
             cfg.nerf[mode]["radiance_field_noise_std"] = noise
         if cfg.train_params.set_automatic_dist_reg_coeficient:  # train_model.py:124-125
@@ -350,8 +357,8 @@ def gen_runiter():
         if dd:
             load_weights(model.fine, False, 12, sharpen)
         ro, rd, rad, tgt = synthetic.make_rays(kind, n, seed=6)
-        for mode in ("train", "validation"):
-            tag = "runiter_%s_%s_%dx%d_%s" % ("dd" if dd else "mip", kind, nc, nf, mode)
+        for mode in ("train",) if dp0 else ("train", "validation"):
+            tag = "runiter_%s_%s_%dx%d%s_%s" % ("dd" if dd else "mip", kind, nc, nf, "dp0" if dp0 else "", mode)
             perturb = bool(cfg.nerf[mode]["perturb"])
             shapes = []
             if perturb:
@@ -394,7 +401,47 @@ def gen_runiter():
                  meta=np.array([nc, nf, sharpen, noise, float(cfg.dataset.near), float(cfg.dataset.far),
                                 float(cfg.train_params.dist_reg_coeficient),
                                 float(cfg.train_params.gaussian_smooth_factor), int(cfg.train_params.pdf_padding)]),
+                 dp_coef=np.array(float(cfg.train_params.dp_coeficient)),
                  **flat_out(out), **rec, **rnd_named, **extra)
+
+
+def gen_fullsize():
+    """BASELINE configs at their stated sizes (validation pass, noise off): only every STRIDE-th ray's outputs are stored,
+    the inputs come from the synthetic seeds.  cfg1: 256 rays x 64 x 64; cfg2: 4096 x (64 + 128) blender; cfg3: config_ff
+    NDC rays; cfg4: config_360, 8192 rays; cfg5: config_blender_mipnerf (one shared MLP)."""
+    for tag, model_type, kind, n, nc, nf in (
+        ("cfg1", "DDNerfModel", "blender", 256, 64, 64),
+        ("cfg2", "DDNerfModel", "blender", 4096, 64, 128),
+        ("cfg3", "DDNerfModel", "llff", 4096, 64, 128),
+        ("cfg4", "DDNerfModel", "real360", 8192, 64, 128),
+        ("cfg5", "GeneralMipNerfModel", "blender", 4096, 64, 128),
+    ):
+        dd = model_type == "DDNerfModel"
+        cfg = load_cfg((CFG_OF if dd else CFG_MIP_OF)[kind], nc, nf, kind)
+        for mode in ("train", "validation"):
+            cfg.nerf[mode]["radiance_field_noise_std"] = 0.0
+        if cfg.train_params.set_automatic_dist_reg_coeficient:
+            cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+        model = getattr(ref_models, cfg.nerf.type)(cfg)
+        load_weights(model.coarse, dd, 11, 20.0)
+        if dd:
+            load_weights(model.fine, False, 12, 20.0)
+        ro, rd, rad, tgt = synthetic.make_rays(kind, n, seed=1)
+        model.eval()
+        with torch.no_grad():
+            out = model.run_iter(T(ro), T(rd), T(rad), mode="validation", rgb_target=T(tgt))
+        stride = max(1, n // 64 - 3)  # 61 at 4096 rays, 125 at 8192, 1 at 256
+        keep = {}
+        for lvl in out:
+            for k in ("rgb", "depth", "acc", "disp", "weights"):
+                keep["o%d_%s" % (lvl, k)] = out[lvl][k][::stride]
+            for k in ("dp_loss", "mus_reg", "sig_reg", "mus_loss", "sig_loss"):
+                if out[lvl].get(k, None) is not None:
+                    keep["o%d_%s" % (lvl, k)] = out[lvl][k]
+        save("fullsize_%s_%s_%s_%d_%dx%d" % (tag, "dd" if dd else "mip", kind, n, nc, nf),
+             meta=np.array([n, nc, nf, 20.0, stride, float(cfg.dataset.near), float(cfg.dataset.far),
+                            float(cfg.train_params.dist_reg_coeficient), float(cfg.train_params.gaussian_smooth_factor),
+                            int(cfg.train_params.pdf_padding)]), **keep)
 
 
 def gen_trainsteps():
@@ -511,6 +558,6 @@ def gen_raygen():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps"]
+    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps", "fullsize"]
     for w in which:
         globals()["gen_" + w]()

@@ -187,7 +187,9 @@ def test_train_step_gradients_match_reference(name):
         # test_dp_loss_backward_matches_reference_grads): the bin search and the clamps of estimate_dp_loss flip with 1e-7
         # changes of the fine samples (another sin/exp implementation in the encoder is enough), and the two-element
         # fc_mu_sigma.bias then moves by 10 %.  That net is therefore held per parameter only loosely and tightly as a whole.
-        chaotic = c["dd"] and pfx == "c"
+        # With the dp term switched off (fixture *dp0*) the coarse net receives only the MSE gradient through
+        # composite_bwd -> MLP backward, and is held to the same 1e-2 as the fine net.
+        chaotic = c["dd"] and pfx == "c" and c.get("dp_coef") != 0.0
         tol = 0.25 if chaotic else 1e-2
         all_mine, all_ref = [], []
         for pname, p in net.named_parameters():

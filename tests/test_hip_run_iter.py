@@ -46,12 +46,17 @@ def build_model(c):
     cfg.train_params.dist_reg_coeficient = c["dist_reg"]
     cfg.train_params.gaussian_smooth_factor = c["smooth"]
     cfg.train_params.pdf_padding = c["pdf_padding"]
+    if c.get("dp_coef") is not None:
+        cfg.train_params.dp_coeficient = c["dp_coef"]
     model = getattr(models, cfg.nerf.type)(cfg)
     model.coarse.load_state_dict({k: torch.from_numpy(v) for k, v in c["sd_coarse"].items()})
     if c["dd"]:
         model.fine.load_state_dict({k: torch.from_numpy(v) for k, v in c["sd_fine"].items()})
     model.to("cuda")
     g = c["g"]
+    if not any(k.startswith("rnd") for k in g) and not c["train"] and c["noise"] == 0:
+        model.rng = ReplayRng([])  # nothing random in this pass
+        return model
     draws = []
     rnd = [g[k] for k in sorted((k for k in g if k.startswith("rnd")), key=lambda s: int(s[3:]))]
     it = iter(rnd)
@@ -127,7 +132,7 @@ def test_run_iter_x3_meets_the_fp32_bar(name):
 @pytest.mark.parametrize("name", ["runiter_dd_blender_64x128_validation", "runiter_dd_llff_16x16_validation", "runiter_mip_blender_64x128_validation"])
 def test_run_iter_bf16_tier(name):
     """The bf16-MFMA MLP is its own tolerance tier ('expect ~1e-2 / >= 40 dB; a tolerance tier to be
-    fixed empirically' -- fixed here at 70 dB / 2e-3): same rays / weights as the fp32 fixtures, RGB PSNR against the
+    fixed empirically' -- fixed here at 75 dB / 1e-3, three times the measured error): same rays / weights as the fp32 fixtures, RGB PSNR against the
     reference's fp32 output."""
     if name not in runiter_names():
         pytest.skip("fixture not generated")
@@ -143,10 +148,10 @@ def test_run_iter_bf16_tier(name):
     for lvl in (0, 1):
         rgb, ref = out[lvl]["rgb"].cpu().numpy(), g["o%d_rgb" % lvl]
         psnr = -10.0 * np.log10(max(float(np.mean((rgb - ref) ** 2)), 1e-20))
-        assert psnr >= 70.0, (lvl, psnr)                      # measured 78-93 dB
-        assert np.abs(rgb - ref).max() <= 2e-3, (lvl, np.abs(rgb - ref).max())   # measured <= 2.7e-4
+        assert psnr >= 75.0, (lvl, psnr)                      # measured 78-93 dB
+        assert np.abs(rgb - ref).max() <= 1e-3, (lvl, np.abs(rgb - ref).max())   # measured <= 2.7e-4: the bar is ~3x that
         depth, dref = out[lvl]["depth"].cpu().numpy(), g["o%d_depth" % lvl]
-        assert np.abs(depth - dref).max() <= 5e-3 * max(1.0, np.abs(dref).max()), lvl   # measured <= 6.9e-4
+        assert np.abs(depth - dref).max() <= 2.5e-3 * max(1.0, np.abs(dref).max()), lvl   # measured <= 6.9e-4
 
 
 def test_validation_reshape_and_chunking():
