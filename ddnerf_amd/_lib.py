@@ -37,7 +37,7 @@ _SIGS = {
     "ddnerf_sample_pdf": (C.c_int, [c_fp] * 5 + [C.c_int] * 4 + [c_fp]),
     "ddnerf_sample_pdf_mu_sigma": (C.c_int, [c_fp] * 8 + [C.c_float, C.c_float, c_fp, c_fp] + [C.c_int] * 4 + [c_fp]),
     "ddnerf_dp_loss_workspace_bytes": (C.c_size_t, [C.c_int]),
-    "ddnerf_dp_loss_forward": (C.c_int, [c_fp] * 8 + [C.c_int] * 4 + [c_fp, c_fp, c_fp]),
+    "ddnerf_dp_loss_forward": (C.c_int, [c_fp] * 8 + [C.c_int] * 4 + [c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_composite_backward": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_dd_head_backward": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_dp_loss_backward": (C.c_int, [c_fp] * 8 + [C.c_int] * 4 + [c_fp] * 5 + [c_fp]),

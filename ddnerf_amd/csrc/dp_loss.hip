@@ -135,22 +135,37 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
     if (live && lane == 0) rowsum[r] = acc;
 }
 
-__global__ void dpl_finish_kernel(const float *__restrict__ rowsum, const int *__restrict__ total, int nf,
-                                  float *__restrict__ loss) {
-    const int R = *total;
+// mean over the kept rows in a fixed order (thread t owns rows t, t+1024, ...; then an LDS tree), and -- when the caller
+// passes the DD head's scalars -- the level-1 `dp_loss` record of the reference, dp * nf + mus_reg + sig_reg
+// (models/models.py:287-289), in the same launch.
+__global__ __launch_bounds__(1024) void dpl_finish_kernel(const float *__restrict__ rowsum, const int *__restrict__ total, int nf,
+                                                         float *__restrict__ loss, const float *__restrict__ reg_scal,
+                                                         float *__restrict__ loss_total) {
+    __shared__ double part[1024];
+    const int R = *total, tid = threadIdx.x;
     double s = 0.0;
-    for (int r = threadIdx.x; r < R; r += 64) s += (double)rowsum[r];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if (threadIdx.x == 0) *loss = R > 0 ? (float)(s / ((double)R * nf)) : 0.0f;
+    for (int r = tid; r < R; r += 1024) s += (double)rowsum[r];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) part[tid] += part[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float l = R > 0 ? (float)(part[0] / ((double)R * nf)) : 0.0f;
+        *loss = l;
+        if (loss_total) *loss_total = (l * (float)nf + reg_scal[2]) + reg_scal[3];
+    }
 }
 
 DDN_EXPORT size_t ddnerf_dp_loss_workspace_bytes(int n) { return n > 0 ? (size_t)n * 12 + 16 : 0; }
 
 DDN_EXPORT int ddnerf_dp_loss_forward(const float *t1, const float *t0, const float *w1, const float *w0,
                                       const float *mus0, const float *sig0, const float *left0, const float *part0,
-                                      int n, int nc, int nf, int blender, float *loss, void *workspace,
-                                      ddnerf_stream_t stream) {
+                                      int n, int nc, int nf, int blender, float *loss, const float *reg_scal,
+                                      float *loss_total, void *workspace, ddnerf_stream_t stream) {
     DDN_REQUIRE(t1 && t0 && w1 && w0 && mus0 && sig0 && left0 && part0 && loss && workspace, DDNERF_E_ARG);
+    DDN_REQUIRE((reg_scal == nullptr) == (loss_total == nullptr), DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && nc > 0 && nf > 0, DDNERF_E_ARG);
     int *keep = (int *)workspace, *rank = keep + n;
     float *rowsum = (float *)(rank + n);
@@ -164,7 +179,7 @@ DDN_EXPORT int ddnerf_dp_loss_forward(const float *t1, const float *t0, const fl
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
     hipLaunchKernelGGL(dpl_rows_kernel, grid, dim3(256), lds, st, t1, t0, w1, w0, mus0, sig0, left0, part0, n, nc, nf,
                        keep, rank, rowsum);
-    hipLaunchKernelGGL(dpl_finish_kernel, dim3(1), dim3(64), 0, st, rowsum, total, nf, loss);
+    hipLaunchKernelGGL(dpl_finish_kernel, dim3(1), dim3(1024), 0, st, rowsum, total, nf, loss, reg_scal, loss_total);
     return ddn_launch_status();
 }
 

@@ -157,6 +157,20 @@ __device__ __forceinline__ float safe_sin(float x) {
     return enc_sin(xr);
 }
 
+// bf16 feature rows (feat_dtype 1) keep 8 significant bits, so their sin / exp come from the hardware transcendentals
+// (v_sin_f32 takes revolutions, |x| / 2 pi <= 51 here leaves 18 fraction bits; v_exp_f32 is 2^x): absolute error < 2e-6,
+// 1/2000 of a bf16 ulp at 1 -- a few results per thousand land on the other side of a rounding boundary (1 bf16 ulp).
+// A third of the instructions of the exact kernels above: the encoder is VALU-bound.
+__device__ __forceinline__ float fast_sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494f); }
+__device__ __forceinline__ float fast_exp_neg(float v) { return __builtin_amdgcn_exp2f(v * 1.44269502f); }
+template <bool FAST>
+__device__ __forceinline__ float safe_sin_t(float x) {
+    if constexpr (!FAST) return safe_sin(x);
+    const float T = 314.159271f;
+    const float xr = (fabsf(x) < T) ? x : remainder_pos(x, T);
+    return fast_sin(xr);
+}
+
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
     return __builtin_bit_cast(unsigned short, b);
@@ -204,8 +218,8 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
                 int f = k / 3, a = k % 3;
                 float v = rays[12 * (size_t)i + 9 + a];
                 float x = v * (float)(1 << f);                                // nerf_helpers.py:163-165
-                row[ls][96 + 3 + f * 6 + a] = enc_sin(x);      // |x| <= 8
-                row[ls][96 + 3 + f * 6 + 3 + a] = enc_sin(x, 1);  // cos
+                row[ls][96 + 3 + f * 6 + a] = BF16 ? fast_sin(x) : enc_sin(x);                       // |x| <= 8
+                row[ls][96 + 3 + f * 6 + 3 + a] = BF16 ? fast_sin(x + 1.57079637f) : enc_sin(x, 1);  // cos
                 if (f == 0) row[ls][96 + a] = v;                              // include_input
                 if (k < 5) row[ls][123 + k] = 0.0f;                           // pad columns
             }
@@ -220,9 +234,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
             float s = (float)(1 << l);
             float y = g_mean[ls][a] * s;                                      // :130
             float yv = g_cov[ls][a] * (s * s);                                // :131
-            float damp = enc_exp_neg(-0.5f * yv);                             // :149  (yv >= 0)
-            row[ls][p] = damp * safe_sin(y);
-            row[ls][48 + p] = damp * safe_sin(y + 1.57079637f);               // :143  y + 0.5*fp32(pi)
+            float damp = BF16 ? fast_exp_neg(-0.5f * yv) : enc_exp_neg(-0.5f * yv);   // :149  (yv >= 0)
+            row[ls][p] = damp * safe_sin_t<BF16>(y);
+            row[ls][48 + p] = damp * safe_sin_t<BF16>(y + 1.57079637f);               // :143  y + 0.5*fp32(pi)
         }
     }
     __syncthreads();

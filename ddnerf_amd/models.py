@@ -241,11 +241,21 @@ class DDNerfModel(GeneralMipNerfModel):
             weights = c["weights"]
             if i == 0:
                 t_vals_0, mus_0, sigmas_0, weights_0 = t_vals, mus, sigmas, weights
+                # models/models.py:292-295: mus / sigmas / smoothed sigmas where the level-0 pdf exceeds 0.1.  Boolean
+                # indexing has a data-dependent size, i.e. a host sync.  ONE stream compaction serves the three records; it
+                # is enqueued here, as soon as its inputs exist, with an asynchronous copy of the length: when the host
+                # asks for it (end of the chunk) the GPU is still busy with the fine pass, so it never runs dry.
+                with torch.no_grad():
+                    records = ops.dd_records_launch(weights_0, mus_0, sigmas_0, smoothed_sigmas)
             dp_loss = None
             if i == 1:
-                dp = F.dp_loss(t_vals.detach(), t_vals_0.detach(), weights.detach(), weights_0, mus_0, sigmas_0,
-                               head["left"].detach(), head["part"].detach(), str(cfg.dataset.type).lower() == "blender")
-                dp_loss = (dp * (t_vals.shape[1] - 1) + mus_reg + sig_reg).unsqueeze(0)          # :287-289
+                dp_args = (t_vals.detach(), t_vals_0.detach(), weights.detach(), weights_0, mus_0, sigmas_0,
+                           head["left"].detach(), head["part"].detach(), str(cfg.dataset.type).lower() == "blender")
+                if torch.is_grad_enabled() and (weights_0.requires_grad or mus_0.requires_grad or sigmas_0.requires_grad):
+                    dp = F.dp_loss(*dp_args)
+                    dp_loss = (dp * (t_vals.shape[1] - 1) + mus_reg + sig_reg).unsqueeze(0)      # :287-289
+                else:  # nothing to differentiate: the record comes out of the loss kernel's last launch
+                    dp_loss = ops.dp_loss_forward(*dp_args, reg_scal=scal)[1]
             # level 1 records the stale level-0 tensors under the level-0 mask, as the reference does (:297-300); the
             # three logging-only records are filled in below, after the fine pass has been enqueued
             ret[i] = {"rgb": c["rgb_map"], "disp": c["disp"], "acc": c["acc"], "weights": weights, "depth": c["depth"],
@@ -256,12 +266,7 @@ class DDNerfModel(GeneralMipNerfModel):
                 ret[i]["sig_loss"] = sig_loss.unsqueeze(0)
                 ret[i]["mus_reg"] = mus_reg.unsqueeze(0)
                 ret[i]["sig_reg"] = sig_reg.unsqueeze(0)
-        # models/models.py:292-295: mus / sigmas / smoothed sigmas where the level-0 pdf exceeds 0.1.  Boolean indexing
-        # has a data-dependent size, i.e. a host sync: ONE stream compaction (ops.dd_records) serves the three records, and it comes last
-        # so that the CPU has already issued the whole fine pass when it blocks (in the middle of the chunk it drained
-        # the queue and the GPU idled while the fine pass was being launched).
-        with torch.no_grad():
-            r_mus, r_sig, r_ssig = ops.dd_records(weights_0, mus_0, sigmas_0, smoothed_sigmas)
+        r_mus, r_sig, r_ssig = ops.dd_records_finish(records)
         rec = {"mus": r_mus, "sigmas": r_sig, "smoothed_sigmas": r_ssig}
         for i in range(2):
             ret[i].update(rec)

@@ -162,9 +162,14 @@ def dd_head(raw6, smooth, dist_reg):
     return d
 
 
-def dd_records(weights, mus, sigmas, ssig):
-    """models/models.py:292-295 -> (mus, sigmas, smoothed_sigmas) of the bins with pdf = w / sum(w) > 0.1, flat row-major.
-    Reads the data-dependent length from the device (one host sync) -- call it when nothing else is left to enqueue."""
+_PINNED = {}
+
+
+def dd_records_launch(weights, mus, sigmas, ssig):
+    """models/models.py:292-295, first half: enqueue the stream compaction of (mus, sigmas, smoothed_sigmas) over the bins with
+    pdf = w / sum(w) > 0.1 and an asynchronous copy of the data-dependent length into pinned host memory.  Returns a
+    ticket for dd_records_finish.  Enqueue it as EARLY as its inputs exist: the host then learns the length while the GPU
+    still works on what was enqueued behind it, instead of draining the queue at the end of the chunk."""
     weights, mus, sigmas, ssig = (_f32c(t, "records") for t in (weights, mus, sigmas, ssig))
     n, nc = weights.shape
     dev = weights.device
@@ -173,8 +178,27 @@ def dd_records(weights, mus, sigmas, ssig):
     ws = torch.empty(_lib.lib().ddnerf_dd_records_workspace_bytes(n, nc), dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().ddnerf_dd_records(_ptr(weights), _ptr(mus), _ptr(sigmas), _ptr(ssig), n, nc, *[_ptr(o) for o in outs],
                                             _ptr(total), _ptr(ws), _stream()), "ddnerf_dd_records")
-    k = int(total.item())
+    ring = _PINNED.setdefault(str(dev), {"slots": [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(8)], "next": 0})
+    host = ring["slots"][ring["next"] % 8]
+    ring["next"] += 1
+    host.copy_(total, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return outs, host, ev, total
+
+
+def dd_records_finish(ticket):
+    """second half: wait for the length (the ONE host sync of a chunk, on an event recorded right behind the compaction) and
+    slice the three records"""
+    outs, host, ev, _total = ticket
+    ev.synchronize()
+    k = int(host[0])
     return tuple(o[:k] for o in outs)
+
+
+def dd_records(weights, mus, sigmas, ssig):
+    """models/models.py:292-295 -> (mus, sigmas, smoothed_sigmas) of the bins with pdf = w / sum(w) > 0.1, flat row-major"""
+    return dd_records_finish(dd_records_launch(weights, mus, sigmas, ssig))
 
 
 def composite_forward(raw, t_vals, rays, noise=None, mus=None, white_bkgd=False, blender=True, want_rgb=False):
@@ -221,17 +245,21 @@ def sample_pdf_mu_sigma(bins, weights, mus, sigmas, part, left, u_base, rnd, nea
     return (out, ind) if want_ind else out
 
 
-def dp_loss_forward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender):
-    """models/dd_utils.py:6-78 -> 0-dim fp32 tensor (kl_div mean over kept rows; 0 if none kept)"""
+def dp_loss_forward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender, reg_scal=None):
+    """models/dd_utils.py:6-78 -> 0-dim fp32 tensor (kl_div mean over kept rows; 0 if none kept).
+    With reg_scal (the DD head's scal[4]) -> (loss, total) where total [1] = loss * nf + mus_reg + sig_reg, the level-1
+    `dp_loss` record of models/models.py:287-289, written by the same launch."""
     t1, t0, w1, w0, mus0, sig0, left0, part0 = (_f32c(t, "dp_loss arg") for t in (t1, t0, w1, w0, mus0, sig0, left0, part0))
     n, nc = w0.shape
     nf = w1.shape[1]
     loss = torch.empty((), dtype=torch.float32, device=w0.device)
+    total = torch.empty(1, dtype=torch.float32, device=w0.device) if reg_scal is not None else None
     ws = torch.empty(_lib.lib().ddnerf_dp_loss_workspace_bytes(n), dtype=torch.uint8, device=w0.device)
     _lib.check(_lib.lib().ddnerf_dp_loss_forward(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0),
-                                                 _ptr(part0), n, nc, nf, int(blender), _ptr(loss), _ptr(ws), _stream()),
+                                                 _ptr(part0), n, nc, nf, int(blender), _ptr(loss), _ptr(_f32c(reg_scal, "reg_scal")),
+                                                 _ptr(total), _ptr(ws), _stream()),
                "ddnerf_dp_loss_forward")
-    return loss
+    return loss if reg_scal is None else (loss, total)
 
 
 # ---- backward entry points ---------------------------------------------------------------------------------

@@ -146,11 +146,14 @@ int ddnerf_sample_pdf_mu_sigma(const float *bins, const float *weights, const fl
  * t1 [n,nf+1], t0 [n,nc+1], w1 [n,nf] (fine weights), w0 [n,nc] (coarse weights), mus0/sig0/left0/part0 [n,nc].
  * blender != 0 applies the row filter sum(w1) > 1e-10, including the reference's un-filtered left_tails_0
  * gather (row r of the FILTERED set reads left0 row r).  loss[0] = kl_div(..., reduction='mean') over the kept
- * rows, 0 when no row is kept.  workspace: ddnerf_dp_loss_workspace_bytes(n) bytes. */
+ * rows, 0 when no row is kept.  workspace: ddnerf_dp_loss_workspace_bytes(n) bytes.
+ * reg_scal / loss_total (both or neither, may be NULL): reg_scal = the DD head's scal[4]; loss_total[0] then receives the
+ * level-1 `dp_loss` record of models/models.py:287-289, loss * nf + mus_reg + sig_reg, from the same launch. */
 size_t ddnerf_dp_loss_workspace_bytes(int n);
 int ddnerf_dp_loss_forward(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,
                            const float *sig0, const float *left0, const float *part0, int n, int nc, int nf,
-                           int blender, float *loss, void *workspace, ddnerf_stream_t stream);
+                           int blender, float *loss, const float *reg_scal, float *loss_total, void *workspace,
+                           ddnerf_stream_t stream);
 
 /* ---- ray generation (the caller immediately upstream of the path) ------------------------------------------
  * get_ray_bundle  general_utils/nerf_helpers.py:67-125: cam2world [host] = 3x4 (or 4x4) row-major pose;
