@@ -176,7 +176,9 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+#ifndef ENC_SPB
 #define ENC_SPB 16  // samples per 256-thread block
+#endif
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ rays, const float *__restrict__ t_vals,
@@ -188,9 +190,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
     const size_t m0 = (size_t)blockIdx.x * ENC_SPB;
     const int tid = threadIdx.x;
 
-    // phase 1: per-sample Gaussian, threads 0..47 (sample = tid/3, axis = tid%3)
-    if (tid < ENC_SPB * 3) {
-        int ls = tid / 3, a = tid % 3;
+    // phase 1: per-sample Gaussian (sample = e/3, axis = e%3)
+    for (int e = tid; e < ENC_SPB * 3; e += 256) {
+        int ls = e / 3, a = e % 3;
         size_t m = m0 + ls;
         if (m < M) {
             int i = (int)(m / S), j = (int)(m % S);
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
             g_cov[ls][a] = tv * qa + rv * nul;                                // :43-45
         }
     }
-    // phase 1b: view-direction encoding, threads 64..(64+16*27): 27 values per sample (same for a ray's samples)
+    // phase 1b: view-direction encoding: 27 values per sample (same for a ray's samples); walked from the far end of the
+    // block so that it lands on other waves than phase 1
     {
-        int t2 = tid - 64;
-        if (t2 >= 0 && t2 < ENC_SPB * 12) {
+        for (int t2 = 255 - tid; t2 < ENC_SPB * 12; t2 += 256) {
             int ls = t2 / 12, k = t2 % 12;  // k: 0..11 -> (freq f = k/3, axis a = k%3), emits sin and cos
             size_t m = m0 + ls;
             if (m < M) {

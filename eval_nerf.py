@@ -70,14 +70,22 @@ def eval_model(basedir, checkpoint_name="checkpoint", extract_ptc=False, save_im
                     results[i][key] = v
                     summary[key].append(v)
         print("Avg time per image: %s" % (sum(times) / (i + 1)))
-    with open(os.path.join(savedir, "results.txt"), "w") as f:  # validation_utils/visualization.py:137-150
-        f.write("summary:\n")
-        for k, v in summary.items():
-            f.write("%s: %s\n" % (k, sum(v) / len(v)))
-        f.write("time_per_image_s: %s\n\nper image:\n" % (sum(times) / max(1, len(times))))
-        for i, dct in results.items():
-            f.write("image %d: %s\n" % (i, dict(dct)))
+    write_dicts_to_a_file(summary, results, os.path.join(savedir, "results.txt"))
     return summary
+
+
+def write_dicts_to_a_file(summary_dict, results_dict, results_file):
+    """The reference's results.txt, line for line (validation_utils/visualization.py:137-150): the overall averages, then
+    one line per image and metric, every number formatted `:.4`."""
+    with open(results_file, "w") as f:
+        print("average overall results:\n", file=f)
+        for key in summary_dict.keys():
+            score = sum(summary_dict[key]) / len(summary_dict[key])
+            print(f"{key}: \t {score:.4}", file=f)
+        print("\nper image results:\n", file=f)
+        for key1 in results_dict.keys():
+            for key2 in results_dict[key1].keys():
+                print(f"image {key1} , {key2}: \t {results_dict[key1][key2]:.4}", file=f)
 
 
 if __name__ == "__main__":

@@ -444,6 +444,38 @@ def gen_fullsize():
                             int(cfg.train_params.pdf_padding)]), **keep)
 
 
+def gen_manifest():
+    """Checkpoint interchange: the reference models' state_dict manifests (name, shape, dtype in order), the
+    Adam state_dict layout after one step, and the key set of the checkpoint dict the reference's training loop saves
+    (train_model.py:248-263; that script cannot be imported here -- tensorboard / imageio are absent -- so the keys are read
+    from its source text as data)."""
+    import json
+    import re
+
+    out = {}
+    for model_type, kind in (("DDNerfModel", "blender"), ("GeneralMipNerfModel", "blender")):
+        dd = model_type == "DDNerfModel"
+        cfg = load_cfg((CFG_OF if dd else CFG_MIP_OF)[kind], 8, 8, kind)
+        model = getattr(ref_models, cfg.nerf.type)(cfg)
+        for tag, net in (("coarse", model.coarse), ("fine", model.fine)):
+            out["%s.%s" % (model_type, tag)] = [[k, list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()]
+        opt = torch.optim.Adam(model.coarse.parameters(), lr=1e-3)
+        sum(p.sum() for p in model.coarse.parameters()).backward()
+        opt.step()
+        osd = opt.state_dict()
+        out["%s.optimizer" % model_type] = {"top": sorted(osd.keys()), "param_group": sorted(osd["param_groups"][0].keys()),
+                                           "n_params": len(osd["param_groups"][0]["params"]),
+                                           "state_entry": sorted(osd["state"][0].keys())}
+    src = open(os.path.join(REF, "train_model.py")).read()
+    blk = src[src.index("checkpoint_dict = {"):src.index("torch.save(", src.index("checkpoint_dict = {"))]
+    out["checkpoint_keys_always"] = re.findall(r'^\s*"(\w+)":', blk, flags=re.M)
+    out["checkpoint_keys_two_networks"] = re.findall(r'checkpoint_dict\["(\w+)"\]', blk)
+    out["checkpoint_file"] = re.search(r'os\.path\.join\(logdir, "([\w.]+)"\)', src[src.index("checkpoint_dict = {"):]).group(1)
+    path = os.path.join(HERE, "checkpoint_manifest.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print("%-40s %8.1f KB" % ("checkpoint_manifest.json", os.path.getsize(path) / 1024))
+
+
 def gen_trainsteps():
     """A few whole optimiser steps of the reference's loop (train_model.py:144-177: run_iter, loss assembly, backward,
     one Adam per network) on fixed rays with replayed randoms: pins that every step evaluates the UPDATED weights."""
@@ -558,6 +590,6 @@ def gen_raygen():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps", "fullsize"]
+    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps", "fullsize", "manifest"]
     for w in which:
         globals()["gen_" + w]()

@@ -40,8 +40,10 @@ def test_train_checkpoint_resume_eval(tmp_path):
     assert train[-1]["psnr_fine"] > train[0]["psnr_fine"] + 3.0, (train[0], train[-1])      # it learns
     assert all(r["loss"] == r["loss"] for r in train)                                        # no NaN
     ck = torch.load(logdir / "checkpoint.ckpt", map_location="cpu")
-    assert {"iter", "model_1_state_dict", "model_2_state_dict", "optimizer_1_state_dict", "optimizer_2_state_dict",
-            "loss", "psnr"} <= set(ck)                                                       # train_model.py:248-263
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "checkpoint_manifest.json")))
+    assert set(ck) == set(man["checkpoint_keys_always"] + man["checkpoint_keys_two_networks"])   # train_model.py:248-263, exactly
+    for key, tag in (("model_1_state_dict", "DDNerfModel.coarse"), ("model_2_state_dict", "DDNerfModel.fine")):
+        assert [[k, list(v.shape), str(v.dtype)] for k, v in ck[key].items()] == man[tag]        # the reference's own manifest
     assert ck["iter"] == 80 and "fc_mu_sigma.weight" in ck["model_1_state_dict"] and "fc_rgb.weight" in ck["model_2_state_dict"]
 
     # resume: starts after the stored iteration, keeps going to the new horizon
@@ -54,8 +56,12 @@ def test_train_checkpoint_resume_eval(tmp_path):
     _run([os.path.join(ROOT, "eval_nerf.py"), "--logdir", str(logdir)], str(tmp_path))
     found = [os.path.join(d, f) for d, _, fs in os.walk(logdir) for f in fs if f == "results.txt"]
     assert found, "eval_nerf.py wrote no results.txt"
-    txt = open(found[0]).read()
-    assert "psnr_fine" in txt and "summary" in txt and "ssim_fine_v2" in txt
+    lines = open(found[0]).read().splitlines()                                           # validation_utils/visualization.py:137-150
+    assert lines[0] == "average overall results:" and lines[1] == "" and "per image results:" in lines
+    head = lines[2:lines.index("per image results:") - 1]
+    assert [l.split(":")[0] for l in head][:2] == ["psnr_coarse", "psnr_fine"] and any(l.startswith("ssim_fine_v2: \t ") for l in head)
+    per = lines[lines.index("per image results:") + 2:]
+    assert per and all(l.startswith("image 0 , ") and ": \t " in l for l in per)
 
     _run([os.path.join(ROOT, "render_video.py"), "--logdir", str(logdir), "--max_frames", "2", "--save_images"], str(tmp_path))
     frames = sorted(os.listdir(logdir / "video" / "frames"))

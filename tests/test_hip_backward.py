@@ -123,7 +123,10 @@ def test_dp_loss_backward_well_conditioned_vs_fp64_autograd(ops, blender):
 @pytest.mark.parametrize("depth,M", [(True, 200), (False, 129), (True, 1000)])
 def test_mlp_backward_vs_autograd(ops, depth, M, mlp_dtype):
     """forward_train + backward_data + weight gradients of one network against torch autograd on the fp32 restatement;
-    "x3" = the split-precision bf16-MFMA training kernels, held to the same bars"""
+    "x3" = the split-precision bf16-MFMA training kernels.  M = 129 is ragged (one sample past a 128-sample tile).
+    x3 activations differ from fp32 ones by ~1e-6, so a pre-activation within that distance of 0 can land on the other side of
+    the ReLU kink, where the derivative is a convention, not a value: samples with a pre-activation inside +-5e-6 (about one
+    sample in twenty: 2,200 units per sample) get a zero upstream gradient in BOTH evaluations; everything else is held tightly."""
     from ddnerf_amd import functions as F
     from ddnerf_amd import base_architectures as BA
 
@@ -137,24 +140,25 @@ def test_mlp_backward_vs_autograd(ops, depth, M, mlp_dtype):
     feat[:, :123] = torch.rand(M, 123, generator=g) * 2 - 1
     feat = feat.cuda()
     G = torch.randn(M, 6 if depth else 4, generator=g).cuda()
+    sdr = {k: v.clone().cuda().requires_grad_() for k, v in sd.items()}
+    pre = []
+    raw_r = R.mlp(feat, sdr, depth, pre)
+    if mlp_dtype == "x3":
+        kink = torch.stack([z.detach().abs().min(dim=1).values for z in pre]).min(dim=0).values < 5e-6
+        assert int(kink.sum()) <= max(3, M // 6)
+        G = G * (~kink)[:, None]
     raw = F.mlp(feat, net)
     (raw * G).sum().backward()
-    sdr = {k: v.clone().cuda().requires_grad_() for k, v in sd.items()}
-    raw_r = R.mlp(feat, sdr, depth)
     close(raw, raw_r, 1e-5, 1e-5)
     (raw_r * G).sum().backward()
     for name, p in net.named_parameters():
         ref = sdr[name].grad
         if mlp_dtype == "fp32":
             close(p.grad, ref, 1e-3, 2e-5 * float(ref.abs().max()))
-        else:
-            # x3 activations differ from fp32 ones by ~1e-6, so a pre-activation within that distance of 0 lands on the
-            # other side of the ReLU kink (measured: 1 of 51,200 per layer): its delta then differs by its whole value and a
-            # the deltas of every earlier layer of that one sample move with it -- at M = 200 samples that is ~1 % of a
-            # first-layer gradient (the derivative AT the kink is a convention, not a value).  Everything else agrees to 1e-5.
+        else:  # products carry a relative error of ~2^-16: a wrong tile, row map or sign bit would be off by O(1)
             a, b = p.grad.double(), ref.double()
-            assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-12, (name, float((a - b).norm() / b.norm()))
-            assert float((a - b).abs().max()) <= 0.3 * float(b.abs().max()), name
+            assert float((a - b).norm()) <= 3e-4 * float(b.norm()) + 1e-12, (name, float((a - b).norm() / b.norm()))
+            assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()), name
     # the parameter gradients are views of ONE flat buffer (the data-parallel bucket)
     flat = net.last_flat_grad
     assert next(net.parameters()).grad.data_ptr() == flat.data_ptr()

@@ -33,15 +33,22 @@ def dd_head(raw6, dist_reg):
     return mus, sig, torch.stack([ml, sl, dist_reg * ml, dist_reg * sl])
 
 
-def mlp(x, sd, depth_head):
+def mlp(x, sd, depth_head, pre=None):
+    """`pre` (a list) collects the pre-activations of the nine ReLU layers"""
     lin = lambda h, n: h @ sd[n + ".weight"].t() + sd[n + ".bias"]
     xyz, dirs = x[:, :96], x[:, 96:123]
     h = xyz
     for i in range(8):
-        h = torch.relu(lin(torch.cat([xyz, h], -1) if i == 5 else h, "layers_xyz.%d" % i))
+        z = lin(torch.cat([xyz, h], -1) if i == 5 else h, "layers_xyz.%d" % i)
+        if pre is not None:
+            pre.append(z)
+        h = torch.relu(z)
     feat = lin(h, "fc_feat")
     alpha = lin(feat, "fc_alpha")
-    hd = torch.relu(lin(torch.cat([feat, dirs], -1), "layers_dir.0"))
+    z = lin(torch.cat([feat, dirs], -1), "layers_dir.0")
+    if pre is not None:
+        pre.append(z)
+    hd = torch.relu(z)
     outs = [lin(hd, "fc_rgb"), alpha]
     if depth_head:
         outs.append(lin(hd, "fc_mu_sigma"))
