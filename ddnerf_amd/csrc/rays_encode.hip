@@ -34,6 +34,7 @@ DDN_EXPORT int ddnerf_pack_rays(const float *origins, const float *directions, c
 // a2  sample_first_cycle   models/samplers.py:30-62.  One thread per fencepost.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float first_cycle_t(float nr, float fr, float tl, int lindisp) {
+    if (lindisp == 2) return tl;                                 // :45-49 get_combined_samples: the row holds absolute depths
     if (!lindisp) return nr * (1.0f - tl) + fr * tl;             // :40
     return 1.0f / (1.0f / nr * (1.0f - tl) + 1.0f / fr * tl);    // :42
 }
@@ -64,6 +65,7 @@ DDN_EXPORT int ddnerf_sample_first_cycle(const float *rays, const float *t_lin, 
                                          int n, int nc, int lindisp, ddnerf_stream_t stream) {
     DDN_REQUIRE(rays && t_lin && t_vals, DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(lindisp >= 0 && lindisp <= 2, DDNERF_E_RANGE);
     size_t total = (size_t)n * (nc + 1);
     hipLaunchKernelGGL(first_cycle_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        rays, t_lin, t_rand, t_vals, n, nc, lindisp);

@@ -15,6 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import base_architectures
+from . import depth_analysis
 from . import functions as F
 from . import ops
 
@@ -48,6 +49,25 @@ def _host_const(kind, a, b, steps, device):
         t = t.to(torch.float32).to(device)
         _const_cache[key] = t
     return t
+
+
+def _combined_row(near, split, far, nc, device):
+    """get_combined_samples (models/samplers.py:6-27): uniform depths up to `split` for the first half of the bins, then
+    log-spaced ones up to far -- one row for every ray, built once on the CPU in fp32 like the reference's CPU path."""
+    key = ("combined", near, split, far, nc, str(device))
+    row = _const_cache.get(key)
+    if row is None:
+        t = torch.linspace(0.0, 1.0, nc // 2 + 1, dtype=torch.float32)
+        uniform = near * (1.0 - t) + split * t
+        max_d = torch.tensor(far, dtype=torch.float32)
+        d = split * (1.0 - t) + max_d * t
+        frac = torch.sort(1 - (torch.log2(d - split + 1) / torch.log2(max_d - split + 1)))[0]
+        log_part = split + frac * (max_d - split)
+        row = torch.cat((uniform, log_part[1:])).to(device)
+        if row.shape[0] != nc + 1:
+            raise ValueError("combined sampling needs an even num_coarse")
+        _const_cache[key] = row
+    return row
 
 
 def get_minibatches(inputs, chunksize=1024 * 8):
@@ -134,11 +154,13 @@ class GeneralMipNerfModel(torch.nn.Module):
     def _first_cycle(self, rays, mode):
         """models/samplers.py:30-62"""
         mc = self._mode_cfg(mode)
-        if self.cfg.dataset.get("combined_sampling_method", False):
-            raise NotImplementedError("dataset.combined_sampling_method is off in every shipped config and not built")
         nc = mc.num_coarse
-        t_lin = _host_const("linspace", 0.0, 1.0, nc + 1, rays.device)
         t_rand = self.rng.rand((rays.shape[0], nc + 1), rays.device) if mc.perturb else None
+        if self.cfg.dataset.get("combined_sampling_method", False):   # models/samplers.py:45-49
+            row = _combined_row(float(self.cfg.dataset.near), float(self.cfg.dataset.combined_split), float(self.cfg.dataset.far), nc,
+                                rays.device)
+            return ops.sample_first_cycle(rays, row, t_rand, 2)
+        t_lin = _host_const("linspace", 0.0, 1.0, nc + 1, rays.device)
         return ops.sample_first_cycle(rays, t_lin, t_rand, bool(mc.lindisp))
 
     def _noise(self, n, S, mode, device):
@@ -160,8 +182,6 @@ class GeneralMipNerfModel(torch.nn.Module):
 
     def predict(self, ray_batch, mode, depth_analysis_validation, rgb_target=None):
         """models/models.py:75-114"""
-        if depth_analysis_validation:
-            raise NotImplementedError("depth-analysis plots are debug visualisation, outside the hot path")
         mc = self._mode_cfg(mode)
         n = ray_batch.shape[0]
         ret = {}
@@ -183,6 +203,10 @@ class GeneralMipNerfModel(torch.nn.Module):
                             bool(mc.white_background), self._is_blender())
             weights = c["weights"]
             ret[i] = {"rgb": c["rgb_map"], "disp": c["disp"], "acc": c["acc"], "weights": weights, "depth": c["depth"]}
+            if depth_analysis_validation:  # :108-112 (plots of a few rays)
+                ret[i]["uniform_incell_pdf_to_plot"] = depth_analysis.uniform_incell_pdf(t_vals, weights, self.cfg.dataset.near,
+                                                                                       self.cfg.dataset.far)
+                ret[i]["t_vals_for_plot"] = t_vals
         return ret
 
 
@@ -204,8 +228,6 @@ class DDNerfModel(GeneralMipNerfModel):
 
     def predict(self, ray_batch, mode, depth_analysis_validation, rgb_target=None):
         """models/models.py:207-322"""
-        if depth_analysis_validation:
-            raise NotImplementedError("depth-analysis plots are debug visualisation, outside the hot path")
         cfg, mc = self.cfg, self._mode_cfg(mode)
         n, dev = ray_batch.shape[0], ray_batch.device
         blender = self._is_blender()
@@ -266,6 +288,15 @@ class DDNerfModel(GeneralMipNerfModel):
                 ret[i]["sig_loss"] = sig_loss.unsqueeze(0)
                 ret[i]["mus_reg"] = mus_reg.unsqueeze(0)
                 ret[i]["sig_reg"] = sig_reg.unsqueeze(0)
+            if depth_analysis_validation:  # :307-319 (plots of a few rays)
+                near, far = cfg.dataset.near, cfg.dataset.far
+                ret[i]["uniform_incell_pdf_to_plot"] = depth_analysis.uniform_incell_pdf(t_vals, weights, near, far)
+                ret[i]["t_vals_for_plot"] = t_vals
+                if i == 1:
+                    ret[i]["gaussian_incell_pdf_to_plot"] = depth_analysis.gaussian_incell_pdf(
+                        t_vals_0, weights_0, mus_0, sigmas_0, head["part"], near, far)
+                    ret[i]["smoothed_gaussian_incell_pdf_to_plot"] = depth_analysis.gaussian_incell_pdf(
+                        t_vals_0, weights_0, mus_0, smoothed_sigmas, head["spart"], near, far)
         r_mus, r_sig, r_ssig = ops.dd_records_finish(records)
         rec = {"mus": r_mus, "sigmas": r_sig, "smoothed_sigmas": r_ssig}
         for i in range(2):

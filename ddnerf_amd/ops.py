@@ -46,7 +46,7 @@ def pack_rays(origins, directions, radii, near, far):
 
 
 def sample_first_cycle(rays, t_lin, t_rand=None, lindisp=False):
-    """models/samplers.py:30-62 -> t_vals [n,nc+1]"""
+    """models/samplers.py:30-62 -> t_vals [n,nc+1]; lindisp=2: t_lin holds the absolute depths of get_combined_samples"""
     rays, t_lin, t_rand = _f32c(rays, "rays"), _f32c(t_lin, "t_lin"), _f32c(t_rand, "t_rand")
     n, nc = rays.shape[0], t_lin.shape[0] - 1
     t = torch.empty((n, nc + 1), dtype=torch.float32, device=rays.device)

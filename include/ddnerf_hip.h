@@ -57,7 +57,9 @@ int ddnerf_pack_rays(const float *origins, const float *directions, const float 
                      float *rays, int n, ddnerf_stream_t stream);
 
 /* a2  sample_first_cycle   models/samplers.py:30-62
- * t_lin [nc+1] = torch.linspace(0,1,nc+1); t_rand [n,nc+1] = torch.rand(...) or NULL (perturb off). */
+ * t_lin [nc+1] = torch.linspace(0,1,nc+1); t_rand [n,nc+1] = torch.rand(...) or NULL (perturb off).
+ * lindisp: 0 linear in depth, 1 linear in disparity, 2 = t_lin already holds the absolute depths of
+ * get_combined_samples (models/samplers.py:6-27, dataset.combined_sampling_method). */
 int ddnerf_sample_first_cycle(const float *rays, const float *t_lin, const float *t_rand, float *t_vals, int n, int nc,
                               int lindisp, ddnerf_stream_t stream);
 

@@ -444,6 +444,49 @@ def gen_fullsize():
                             int(cfg.train_params.pdf_padding)]), **keep)
 
 
+def gen_depthanalysis():
+    """run_iter(depth_analysis_validation=True) (models/models.py:108-112, 307-319) and get_combined_samples
+    (models/samplers.py:6-27, dataset.combined_sampling_method) on a handful of rays."""
+    for model_type, kind, n, nc, nf in (("DDNerfModel", "blender", 6, 16, 16), ("GeneralMipNerfModel", "blender", 6, 16, 16)):
+        dd = model_type == "DDNerfModel"
+        cfg = load_cfg((CFG_OF if dd else CFG_MIP_OF)[kind], nc, nf, kind)
+        for mode in ("train", "validation"):
+            cfg.nerf[mode]["radiance_field_noise_std"] = 0.0
+        if cfg.train_params.set_automatic_dist_reg_coeficient:
+            cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+        model = getattr(ref_models, cfg.nerf.type)(cfg)
+        load_weights(model.coarse, dd, 11, 8.0)
+        if dd:
+            load_weights(model.fine, False, 12, 8.0)
+        ro, rd, rad, tgt = synthetic.make_rays(kind, n, seed=4)
+        model.eval()
+        with torch.no_grad():
+            out = model.run_iter(T(ro), T(rd), T(rad), mode="validation", depth_analysis_validation=True, rgb_target=T(tgt))
+        keep = {}
+        for lvl in out:
+            for k, v in out[lvl].items():
+                if isinstance(v, torch.Tensor) and ("to_plot" in k or "for_plot" in k or k in ("rgb", "depth")):
+                    keep["o%d_%s" % (lvl, k)] = v
+        save("depthanalysis_%s_%s" % ("dd" if dd else "mip", kind), ro=ro, rd=rd, rad=rad,
+             meta=np.array([nc, nf, 8.0, 0.0, float(cfg.dataset.near), float(cfg.dataset.far), float(cfg.train_params.dist_reg_coeficient),
+                            float(cfg.train_params.gaussian_smooth_factor), int(cfg.train_params.pdf_padding)]), **keep)
+    # combined sampling (config_360 with the switch on), perturb off and on
+    cfg = load_cfg(CFG_OF["real360"], 16, 16, "real360")
+    cfg.dataset.combined_sampling_method = True
+    near = torch.full((5, 1), float(cfg.dataset.near))
+    far = torch.full((5, 1), float(cfg.dataset.far))
+    rec = {}
+    for mode, perturb in (("validation", False), ("train", True)):
+        cfg.nerf[mode]["perturb"] = perturb
+        torch.manual_seed(9)
+        rnd = torch.rand(5, 17) if perturb else None
+        torch.manual_seed(9)
+        rec["t_%s" % mode] = ref_samplers.sample_first_cycle(cfg, near, far, mode)
+        if rnd is not None:
+            rec["rnd_%s" % mode] = rnd
+    save("combined_first_cycle", meta=np.array([16, float(cfg.dataset.near), float(cfg.dataset.far), float(cfg.dataset.combined_split)]), **rec)
+
+
 def gen_manifest():
     """Checkpoint interchange: the reference models' state_dict manifests (name, shape, dtype in order), the
     Adam state_dict layout after one step, and the key set of the checkpoint dict the reference's training loop saves
@@ -590,6 +633,6 @@ def gen_raygen():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps", "fullsize", "manifest"]
+    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps", "fullsize", "manifest", "depthanalysis"]
     for w in which:
         globals()["gen_" + w]()
