@@ -433,8 +433,10 @@ __device__ __forceinline__ void repack_step(Regs &r) {
         } else {
             if constexpr (out_in_a<L>()) {
                 u32x4 w = __builtin_bit_cast(u32x4, r.HA[C][b / 2]);
-                w[2 * (b & 1)] = to_agpr_here(r.rp[C][0]);
-                w[2 * (b & 1) + 1] = to_agpr_here(r.rp[C][1]);
+                unsigned a0, a1;  // both words in ONE asm statement: hipcc pads a wait state between two asm statements
+                asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3" : "=a"(a0), "=a"(a1) : "v"(r.rp[C][0]), "v"(r.rp[C][1]));
+                w[2 * (b & 1)] = a0;
+                w[2 * (b & 1) + 1] = a1;
                 r.HA[C][b / 2] = __builtin_bit_cast(bf16x8, w);
                 // the fragment is complete: from here on it is ONE 128-bit value born in the accumulator half, which is
                 // what the MFMA asm asks for -- otherwise LLVM assembles some fragments in arch VGPRs and copies them
@@ -450,6 +452,13 @@ __device__ __forceinline__ void repack_step(Regs &r) {
         }
     }
 }
+
+// Feature rows are read exactly once: a non-temporal load keeps them from displacing the weight image in the XCD's L2
+#ifdef BF16_FEAT_PLAIN
+#define FEAT_LOAD(p) (*(p))
+#else
+#define FEAT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 
 // feature events: the NEXT tile's features travel global -> Xt (arch VGPRs) -> X (accumulator half), one 32-column
 // group at a time, at blocks where the current tile no longer needs that group
@@ -480,7 +489,7 @@ __device__ __forceinline__ void x_gap(Regs &r, const char *__restrict__ feat, co
     if constexpr (ev >= 1 && ev <= 4) {
 #pragma unroll
         for (int c = 2 * HALF; c < 2 * HALF + 2; ++c)
-            r.Xt[c] = *(const bf16x8 *)(feat + (size_t)xoff[c] + 64 * (ev - 1) + 16 * (lane >> 4));
+            r.Xt[c] = FEAT_LOAD((const bf16x8 *)(feat + (size_t)xoff[c] + 64 * (ev - 1) + 16 * (lane >> 4)));
     } else if constexpr (ev >= 5) {
 #pragma unroll
         for (int c = 2 * HALF; c < 2 * HALF + 2; ++c) r.X[c][ev - 5] = to_agpr8(r.Xt[c]);
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void mlp_bf16_fwd_kernel(const char 
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t[c][q] = *(const bf16x8 *)(feat + (size_t)xo[c] + 64 * q + 16 * g);
+            for (int q = 0; q < 4; ++q) t[c][q] = FEAT_LOAD((const bf16x8 *)(feat + (size_t)xo[c] + 64 * q + 16 * g));
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll

@@ -26,6 +26,28 @@ extern "C" __global__ __launch_bounds__(256) void calib_stream(const float *__re
     }
     out[(long)blockIdx.x * 256 + threadIdx.x] = s;
 }
+// (c) the persistent bf16 MLP kernel's pattern: bf16 [M,128] rows (256 B); lane (j = l & 15, g = l >> 4) reads 16 B at byte
+// 64 q + 16 g of row 16 c + j, for q = 0..3 and column blocks c = 0..3 of the wave's 64 samples: every instruction fetches 64-byte
+// quarter rows
+extern "C" __global__ __launch_bounds__(256) void calib_bf16rows(const unsigned short *__restrict__ feat, float *__restrict__ out, long M) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const long m = (long)blockIdx.x * 256 + wave * 64 + c * 16 + j;
+        if (m >= M) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *(const f32x4 *)((const char *)feat + (size_t)m * 256 + 64 * q + 16 * g);
+            s += v.x + v.y + v.z + v.w;
+        }
+    }
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+extern "C" int run_bf16rows(const void *feat, float *out, long M, void *st) {
+    hipLaunchKernelGGL(calib_bf16rows, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)st, (const unsigned short *)feat, out, M);
+    return (int)hipGetLastError();
+}
 extern "C" int run_rows(const float *feat, float *out, long M, void *st) {
     hipLaunchKernelGGL(calib_rows, dim3((M + 127) / 128), dim3(256), 0, (hipStream_t)st, feat, out, M);
     return (int)hipGetLastError();

@@ -1,5 +1,6 @@
-"""gpurun_out/pmc/* (scratch/pmc_all.sh) -> profiles/r01_hbm_traffic_<mlp>.json, profiles/r01_pmc_mfma.json"""
-import csv, collections, json, os, re
+"""gpurun_out/pmc/* (scratch/pmc_all.sh) -> profiles/<round>_hbm_traffic_<mlp>.json, profiles/<round>_pmc_mfma.json (round: argv[1], default r02)"""
+import csv, collections, hashlib, json, os, re, sys
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "gpurun_out", "pmc")
 def short(n):
@@ -11,7 +12,8 @@ def agg(path):
         d[short(r["Kernel_Name"])][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size"])))
     return d
 calib = agg(os.path.join(P, "calib", "c_counter_collection.csv"))
-cal = {k: sum(v for v, _, _ in calib[k]["FETCH_SIZE"]) / len(calib[k]["FETCH_SIZE"]) for k in ("calib_rows", "calib_stream")}
+cal = {k: sum(v for v, _, _ in calib[k]["FETCH_SIZE"]) / len(calib[k]["FETCH_SIZE"]) for k in ("calib_rows", "calib_stream", "calib_bf16rows")}
+BF16_FACTOR = cal["calib_bf16rows"] / (524288 * 256 / 1024)   # raw FETCH_SIZE per true byte in the persistent bf16 kernel's row pattern
 TRUE_KB = 524288 * 512 / 1024
 mfma = {}
 for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512 + 16)), ("bf16", "void mlp_bf16_fwd_kernel<false>", 524288 * (256 + 16)),
@@ -25,20 +27,34 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
         table[k] = {"launches": max(len(fe), len(wr)), "FETCH_SIZE_raw_KB": round(sum(fe) / len(fe), 1) if fe else None,
                     "WRITE_SIZE_KB": round(sum(wr) / len(wr), 1) if wr else None}
     fk = table[kern]
-    traffic = (2 * fk["FETCH_SIZE_raw_KB"] + fk["WRITE_SIZE_KB"]) * 1024
-    out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of `python3 bench.py --mlp %s --steps 4 --warmup 1 "
-                   "--no-cpu-baseline --no-bf16-tier` (MI355X, round 1; scratch/pmc_all.sh, scratch/parse_pmc.py). Units KB, mean per launch. "
+    # fp32 / x3: the guide's gfx950 rule (FETCH_SIZE doubled; calibrated 0.563 for their lane-per-row pattern, kept at the
+    # conservative 2x).  bf16: the kernel reads 64-byte quarter rows, which the counter tallies differently: divide by the
+    # factor measured on the same pattern in the same call.
+    fetch_true_kb = fk["FETCH_SIZE_raw_KB"] / BF16_FACTOR if mlp == "bf16" else 2 * fk["FETCH_SIZE_raw_KB"]
+    traffic = (fetch_true_kb + fk["WRITE_SIZE_KB"]) * 1024
+    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_common.h"], "x3": ["mlp_x3.hip", "mlp_x3_common.h", "mlp_bf16_common.h"]}[mlp]
+    digest = hashlib.md5()
+    for f_ in srcs:
+        digest.update(open(os.path.join(R, "ddnerf_amd", "csrc", f_), "rb").read())
+    out = {"kernel_source_md5": digest.hexdigest(),
+           "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of `python3 bench.py --mlp %s --steps 4 --warmup 1 "
+                   "--no-cpu-baseline --no-bf16-tier` (MI355X, this round; scratch/pmc_all.sh, scratch/parse_pmc.py). kernel_source_md5 = md5 of the kernel's "
+                   "source files at collection time (bench.py quotes the traffic only for that source). Units KB, mean per launch. "
                    "Corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: on gfx950 FETCH_SIZE reports half of the bytes of "
                    "16-B-per-lane reads, so it is DOUBLED; WRITE_SIZE is exact. Calibrated in the same call (scratch/calib): a 268,435,456-byte "
                    "[524288,128] fp32 buffer read exactly once gives raw FETCH_SIZE %.0f KB with a coalesced float4 stream (0.500 of the bytes) and "
                    "%.0f KB with the MLP kernels' access pattern (lane = sample, 16-B pieces of its own 512-B row: %.3f of the bytes)."
                    % (mlp, cal["calib_stream"], cal["calib_rows"], cal["calib_rows"] / TRUE_KB),
+           "fetch_calibration": {"calib_stream_raw_over_true": round(cal["calib_stream"] / TRUE_KB, 4), "calib_rows_raw_over_true": round(cal["calib_rows"] / TRUE_KB, 4),
+                                 "calib_bf16rows_raw_over_true": round(BF16_FACTOR, 4), "applied": "raw / calib_bf16rows" if mlp == "bf16" else "raw x 2"},
            "fine_mlp_%s_fwd_hbm_bytes_per_launch" % mlp: traffic, "algorithmic_bytes_per_launch": algo,
-           "why_above_algorithmic": "by design the kernel re-reads the 96 xyz feature columns for the skip layer instead of holding 48 registers across "
-                                    "four layers (+201 MB fp32 / +101 MB bf16 if it misses L2), and 4096 (fp32) / 2048 (bf16) workgroups each stream the whole "
-                                    "weight image (2.6 MB / 1.3 MB) through L2; at the measured launch time this is < 2 % (fp32) / < 10 % (bf16) of HBM bandwidth",
+           "why_above_algorithmic": ("the persistent bf16 kernel reads every feature row once and keeps it in registers; what is left above the algorithmic "
+                                     "bytes is the packed weight image (1.4 MB per XCD) and write granularity" if mlp == "bf16" else
+                                     "by design the fp32 / x3 kernels re-read the 96 xyz feature columns for the skip layer instead of holding 48 registers "
+                                     "across four layers (+201 MB if it misses L2), and 4096 workgroups each stream the whole weight image (2.6 MB) through L2; "
+                                     "at the measured launch time this is < 2 % (fp32) / < 6 % (x3) of HBM bandwidth"),
            "kernels": table}
-    json.dump(out, open(os.path.join(R, "profiles", "r01_hbm_traffic_%s.json" % mlp), "w"), indent=1)
+    json.dump(out, open(os.path.join(R, "profiles", ROUND + "_hbm_traffic_%s.json" % mlp), "w"), indent=1)
     print(mlp, "traffic MB", traffic / 1e6, "algorithmic MB", algo / 1e6)
     m = agg(os.path.join(P, "mfma_" + mlp, "c_counter_collection.csv"))
     for k in m:
@@ -55,6 +71,6 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
 json.dump({"note": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE on bench.py (scratch/pmc_all.sh). "
                    "GRBM_GUI_ACTIVE is summed over the 8 XCDs (divided by 8 here); clock = GRBM_GUI_ACTIVE / kernel duration; MFMA pipe utilisation = "
                    "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) (the counter sums busy cycles over all SIMDs: 64 per 32x32x2 fp32 MFMA, "
-                   "32 per 32x32x16 bf16 MFMA); fraction of the nominal peak = utilisation x clock / 2.4 GHz. Kernels run ~10 % slower under PMC collection "
-                   "than in bench.py's un-profiled HIP-event timing.", "kernels": mfma}, open(os.path.join(R, "profiles", "r01_pmc_mfma.json"), "w"), indent=1)
+                   "32 per 32x32x16 and 16 per 16x16x32 bf16 MFMA); fraction of the nominal peak = utilisation x clock / 2.4 GHz. Kernels run ~10 % slower under PMC collection "
+                   "than in bench.py's un-profiled HIP-event timing.", "kernels": mfma}, open(os.path.join(R, "profiles", ROUND + "_pmc_mfma.json"), "w"), indent=1)
 print(json.dumps(mfma, indent=1))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC evidence (MFMA utilisation, clocks, HBM bytes) for the MLP kernels; run on the GPU box from the repo root
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?}; O=$R/gpurun_out/pmc; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib -o c -- python3 $R/scratch/calib/calib.py > $O/calib.log 2>&1
 for mlp in fp32 bf16 x3; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # run on the GPU box from the repo root: refreshes the numbers under gpurun_out/refresh (copied into profiles/ by hand)
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/refresh; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?}; O=$R/gpurun_out/refresh; mkdir -p $O
 cd $R
 timeout -k 10 600 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
