@@ -5,7 +5,8 @@ nothing around an asm statement: the wait states between a VALU write and an MFM
 MFMA and a VALU write to one of its sources, and between an MFMA and a reader of its result exist only because the
 written instruction order keeps such pairs far apart.  A compiler-inserted register copy next to an MFMA would break that
 silently (it did once: outputs off by 1e-3).  This script scans the compiler's assembly of the kernel and fails the build
-when a dependent pair comes closer than the distances below (counted in instructions; `s_nop n` counts n + 1).
+when a dependent pair comes closer than the distances below (counted in wait states: one per instruction, n + 1 for
+`s_nop n`, 2 for an MFMA in between, which holds the issue port for 8 cycles).
 
 usage: check_asm_hazards.py file.s [kernel-name-substring]"""
 import re
@@ -67,7 +68,8 @@ def check(path, kernel="mlp_bf16_fwd_kernel"):
     if not any(m.startswith("v_mfma") for m, _, _ in ins):
         raise SystemExit("check_asm_hazards: no MFMA found in %s (kernel %s)" % (path, kernel))
     du = [defs_uses(m, o) for m, o, _ in ins]
-    slots = [int(o[0]) + 1 if m == "s_nop" and o else 1 for m, o, _ in ins]
+    # wait states an instruction contributes to a distance: s_nop n -> n + 1; an MFMA holds the issue port for 8 cycles -> 2
+    slots = [int(o[0]) + 1 if m == "s_nop" and o else (2 if m.startswith("v_mfma") else 1) for m, o, _ in ins]
     bad = []
     for i, (m, o, text) in enumerate(ins):
         if not m.startswith("v_mfma"):

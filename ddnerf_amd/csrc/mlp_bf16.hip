@@ -35,6 +35,7 @@
 #define M16_PLANES 1
 #define M16_SYM(x) ddnerf_mlp_bf16_##x
 #define M16_KERNEL mlp_bf16_fwd_kernel
+#define M16_FEAT_T void
 #define M16_PACK_KERNEL mlp_bf16_pack_kernel
 #define NSTAGE 40
 // stage -> (layer, first block, blocks); the last stage also carries the heads block

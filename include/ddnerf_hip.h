@@ -91,7 +91,8 @@ int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head
 /* K2 "x3": the same network on the bf16 matrix cores at fp32-class accuracy -- every fp32 weight and activation is split
  * exactly into hi + lo bf16, three MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulation: outputs within ~1e-6
  * of an fp64 evaluation (exact-fp32 kernel 6e-8, plain bf16 6e-4).  feat is the fp32 [M,128] feature matrix in natural
- * column order (as for ddnerf_mlp_f32_forward); replaces the same reference functions. */
+ * column order (as for ddnerf_mlp_f32_forward); replaces the same reference functions.  Inference kernel (persistent,
+ * v_mfma_f32_16x16x32_bf16; mlp_x3_fwd.hip). */
 size_t ddnerf_mlp_x3_packed_bytes(int depth_head);
 int ddnerf_mlp_x3_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head, float *raw, long M,
@@ -99,10 +100,13 @@ int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head,
 
 /* x3 training kernels (same network, same accuracy class): the forward that records what the backward needs, the W^T
  * images, and the fused backward-data pass -- drop-ins for ddnerf_mlp_f32_forward_train / _pack_t / _backward_data.
+ *   packed: the training forward's own weight image (ddnerf_mlp_x3_train_pack; not the inference kernel's)
  *   acts  [ddnerf_mlp_act_rows(), ld] fp32, [feature][sample] (row map as for the fp32 kernels); ld = M rounded up to 128
  *   bits  [160, ld] uint16: word (tile*2 + lane_half) of a sample = signs of that lane's 16 values of 32-row tile `tile`
  *         (relu' for the backward pass; 2 bytes instead of the 64-byte fp32 tile)
  *   deltas [ddnerf_mlp_act_rows(), ld] fp32: every layer's pre-activation gradient, rows as in `acts`; rows 2432.. = d(raw) */
+size_t ddnerf_mlp_x3_train_packed_bytes(int depth_head);
+int ddnerf_mlp_x3_train_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_x3_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts, void *bits,
                                 long M, long ld, ddnerf_stream_t stream);
 size_t ddnerf_mlp_x3_packed_t_bytes(int depth_head);

@@ -28,11 +28,12 @@ for so in libs:
         f = getattr(L, "ddnerf_mlp_%s_forward" % infix); f.argtypes = [V, V, C.c_int, V, C.c_long, V]
         runs.append((so, lambda f=f, packed=packed: f(fb.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)))
     elif kind == "x3":
-        L.ddnerf_mlp_x3_packed_bytes.restype = C.c_size_t
-        packed = torch.empty(L.ddnerf_mlp_x3_packed_bytes(0), dtype=torch.uint8, device="cuda")
-        L.ddnerf_mlp_x3_pack.argtypes = [V, C.c_int, V, V]
-        assert L.ddnerf_mlp_x3_pack(flat.data_ptr(), 0, packed.data_ptr(), st) == 0
-        f = L.ddnerf_mlp_x3_forward; f.argtypes = [V, V, C.c_int, V, C.c_long, V]
+        infix = infix or "x3"
+        pb = getattr(L, "ddnerf_mlp_%s_packed_bytes" % infix); pb.restype = C.c_size_t
+        packed = torch.empty(pb(0), dtype=torch.uint8, device="cuda")
+        pk = getattr(L, "ddnerf_mlp_%s_pack" % infix); pk.argtypes = [V, C.c_int, V, V]
+        assert pk(flat.data_ptr(), 0, packed.data_ptr(), st) == 0
+        f = getattr(L, "ddnerf_mlp_%s_forward" % infix); f.argtypes = [V, V, C.c_int, V, C.c_long, V]
         runs.append((so, lambda f=f, packed=packed: f(feat.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)))
     else:
         L.ddnerf_mlp_f32_packed_floats.restype = C.c_size_t

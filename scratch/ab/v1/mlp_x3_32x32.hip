@@ -15,7 +15,7 @@
 // share every LDS-staged weight byte; per k-step a wave issues 2 ds_read_b128 and 3 MFMAs (96 matrix-pipe cycles), so
 // LDS reads sit at a third of the array's rate and the accumulator -> hi/lo re-pack (8 VALU ops per value pair) has
 // 48 MFMAs per tile to hide behind.
-#include "mlp_x3_common.h"
+#include "../../../ddnerf_amd/csrc/mlp_x3_common.h"
 
 struct PlanX {
     int w_src[13];
@@ -42,7 +42,7 @@ static PlanX make_plan_x(int depth_head) {
     return p;
 }
 
-DDN_EXPORT size_t ddnerf_mlp_x3_train_packed_bytes(int depth_head) { return (size_t)make_plan_x(depth_head).total_bytes; }
+DDN_EXPORT size_t ddnerf_mlp_x3v1_packed_bytes(int depth_head) { return (size_t)make_plan_x(depth_head).total_bytes; }
 
 // same source mapping as the fp32 / bf16 kernels (see mlp_f32.hip)
 __device__ __forceinline__ float srcw(const float *__restrict__ P, const PlanX &pl, int l, int o, int c) {
@@ -71,7 +71,7 @@ __global__ void mlp_x3_pack_kernel(const float *__restrict__ P, PlanX pl, unsign
                                           [&](int l, int o) { return srcb(P, pl, l, o); });
 }
 
-DDN_EXPORT int ddnerf_mlp_x3_train_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
+DDN_EXPORT int ddnerf_mlp_x3v1_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
     DDN_REQUIRE(params && packed, DDNERF_E_ARG);
     DDN_REQUIRE(ddn_aligned(packed, 16), DDNERF_E_ALIGN);
     PlanX pl = make_plan_x(depth_head);
@@ -82,7 +82,7 @@ DDN_EXPORT int ddnerf_mlp_x3_train_pack(const float *params, int depth_head, voi
 }
 
 // ---- fused forward ----------------------------------------------------------------------------------------
-// MODE 0: inference (ddnerf_mlp_x3_forward).  MODE 1: the training forward, which also records every layer's output
+// MODE 0: inference (ddnerf_mlp_x3v1_forward).  MODE 1: the training forward, which also records every layer's output
 // transposed (`acts`, the layout of mlp_f32_train.hip) and its sign bits (`bits`) for the backward pass.
 template <bool DEPTH_HEAD, int MODE, int PFD>
 __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_fwd_kernel(const float *__restrict__ feat,
@@ -160,9 +160,24 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_fwd_kernel(const floa
 #endif
 // vmcnt retires in order: the staging ring must also cover the acknowledgement of the activation stores
 
+DDN_EXPORT int ddnerf_mlp_x3v1_forward(const float *feat, const void *packed, int depth_head, float *raw, long M,
+                                     ddnerf_stream_t stream) {
+    DDN_REQUIRE(feat && packed && raw, DDNERF_E_ARG);
+    DDN_REQUIRE(M > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16), DDNERF_E_ALIGN);
+    dim3 grid((unsigned)((M + X3_WG_SAMPLES - 1) / X3_WG_SAMPLES));
+    if (depth_head)
+        hipLaunchKernelGGL((mlp_x3_fwd_kernel<true, 0, X3_PFD>), grid, dim3(X3_WG_THREADS), 0, (hipStream_t)stream, feat,
+                           (const char *)packed, raw, nullptr, nullptr, M, 0L);
+    else
+        hipLaunchKernelGGL((mlp_x3_fwd_kernel<false, 0, X3_PFD>), grid, dim3(X3_WG_THREADS), 0, (hipStream_t)stream, feat,
+                           (const char *)packed, raw, nullptr, nullptr, M, 0L);
+    return ddn_launch_status();
+}
+
 // The training forward: also writes acts [2560, ld] (fp32, [feature][sample], row map of mlp_f32_train.hip) and
 // bits [160, ld] (u16: word (tile * 2 + lane half) of a sample holds the signs of that lane's 16 values of the tile).
-DDN_EXPORT int ddnerf_mlp_x3_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts,
+DDN_EXPORT int ddnerf_mlp_x3v1_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts,
                                            void *bits, long M, long ld, ddnerf_stream_t stream) {
     DDN_REQUIRE(feat && packed && raw && acts && bits, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);

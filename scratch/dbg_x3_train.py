@@ -10,7 +10,7 @@ torch.manual_seed(0)
 feat = torch.zeros(M, 128, device="cuda"); feat[:, :123] = torch.rand(M, 123, device="cuda") * 2 - 1
 G = torch.randn(M, 6, device="cuda")
 raw_f, acts_f = ops.mlp_f32_forward_train(feat, ops.mlp_f32_pack(flat, depth), depth)
-raw_x, acts_x, bits = ops.mlp_x3_forward_train(feat, ops.mlp_x3_pack(flat, depth), depth)
+raw_x, acts_x, bits = ops.mlp_x3_forward_train(feat, ops.mlp_x3_train_pack(flat, depth), depth)
 print("raw err", float((raw_f - raw_x).abs().max()))
 for r0, r1, nm in [(0, 256, "l0"), (256, 512, "l1"), (1280, 1536, "l5"), (1792, 2048, "l7"), (2048, 2304, "feat"), (2304, 2432, "dir"), (2432, 2560, "x")]:
     a, b = acts_f[r0:r1, :M], acts_x[r0:r1, :M]
