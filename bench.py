@@ -371,20 +371,27 @@ def main(argv=None):
 
 
 def train_roofline(args, cfg, step_s):
-    """Whole-step MFMA roofline of a training step: algorithmic FLOP of the forward, the backward-data pass (no input
-    gradient for the first layer and the feature columns) and the weight gradients of both networks / step time."""
+    """Whole-step MFMA roofline of a training step: the time the step's algorithmic FLOP would take at the dense MFMA peak of
+    the unit each pass runs on, over the measured step time.  Forward and backward-data (no input gradient for the first
+    layer, the skip's xyz columns and the dir columns) run on the fp32 matrix cores (--mlp fp32) or as three bf16 MFMAs per
+    product (--mlp x3); the weight gradients always run as three bf16 MFMAs per product."""
     dd = cfg.nerf.type == "DDNerfModel"
     m_c, m_f = args.rays * args.coarse, args.rays * args.fine
     f_c, f_f = (FLOP_COARSE_DD if dd else FLOP_FINE), FLOP_FINE
-    first = 2 * (96 * 256 + 96 * 256 + 27 * 128)  # products that need no input gradient: layer 0, the skip's xyz and the dir columns
-    flop = m_c * (3 * f_c - first) + m_f * (3 * f_f - first)
-    issued = 3 if args.mlp == "x3" else 1
-    peak = PEAK["x3"] if args.mlp == "x3" else PEAK["fp32"]
-    ach = issued * flop / step_s / 1e12
+    first = 2 * (96 * 256 + 96 * 256 + 27 * 128)
+    fwd = m_c * f_c + m_f * f_f
+    bwd = m_c * (f_c - first) + m_f * (f_f - first)
+    wgrad = fwd
+    if args.mlp == "x3":
+        ideal = 3 * (fwd + bwd + wgrad) / (PEAK["x3"] * 1e12)
+    else:
+        ideal = (fwd + bwd) / (PEAK["fp32"] * 1e12) + 3 * wgrad / (PEAK["x3"] * 1e12)
     return {"bound": "mfma", "kernel": "whole training step (forward + backward-data + weight gradients of both networks)",
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "algorithmic_flop_per_step": flop, "note": "x3: three bf16 MFMAs issued per product" if args.mlp == "x3" else
-            "fp32 MFMA for forward / backward-data; weight gradients run on the bf16 cores (x3) and are counted once"}
+            "algorithmic_flop_per_step": fwd + bwd + wgrad, "ideal_ms": round(ideal * 1e3, 4), "step_ms": round(step_s * 1e3, 4),
+            "frac": round(ideal / step_s, 4), "unit": "fraction of the step time the FLOP need at the dense MFMA peaks",
+            "peaks_tflops": {"fp32_mfma": PEAK["fp32"], "bf16_mfma": PEAK["x3"]},
+            "note": ("forward / backward-data / weight gradients all as three bf16 MFMAs per product" if args.mlp == "x3" else
+                     "forward / backward-data on the fp32 matrix cores, weight gradients as three bf16 MFMAs per product")}
 
 
 if __name__ == "__main__":
