@@ -17,7 +17,9 @@
 // LDS-DMA into a three-deep raw fp32 ring + a conversion pass -- a 16-sample row segment is 64 B, half an HBM line, and
 // 160 KiB of LDS has no room for a deeper ring of 32-sample tiles; a second register set for a second tile in flight
 // does not fit either (244 of 256 registers are in use at 8 waves per CU); two 256-thread workgroups per CU, each with
-// half of the out-rows and its own tile pipeline, made a training step 1.4 ms slower.
+// half of the out-rows and its own tile pipeline, made a training step 1.4 ms slower.  Round 2: a 4-wave configuration (one
+// wave per SIMD, 4 x 4 accumulator tiles per wave) fits one tile in flight in 448 registers and made the step 0.8 ms slower;
+// with two tiles in flight it needs more than the 512 registers (319 spills).
 #include "mlp_f32_common.h"
 #include "wgrad_reduce.h"
 
