@@ -47,8 +47,8 @@ CONFIGS = {
     "config_ff_mipnerf.yml": ("llff", "fp32", 4096),
     "config_360_mipnerf.yml": ("real360", "fp32", 8192),
 }
-KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_common.h"],
-                  "x3": ["mlp_x3.hip", "mlp_x3_common.h", "mlp_bf16_common.h"]}
+KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+                  "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
 
 
 def parse(argv=None):
