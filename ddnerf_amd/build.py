@@ -24,6 +24,7 @@ SOURCES = {
     "mlp_f32_train.hip": [],
     "mlp_f32_wgrad.hip": [],
     "mlp_x3_wgrad.hip": [],
+    "mlp_x3_wgrad_packed.hip": [],
     # accumulators in arch VGPRs (the VALU re-pack reads them), B files in the accumulator half: see mlp_bf16.hip
     "mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "mlp_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

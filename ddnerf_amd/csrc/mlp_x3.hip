@@ -83,7 +83,8 @@ DDN_EXPORT int ddnerf_mlp_x3_train_pack(const float *params, int depth_head, voi
 
 // ---- fused forward ----------------------------------------------------------------------------------------
 // MODE 0: inference (ddnerf_mlp_x3_forward).  MODE 1: the training forward, which also records every layer's output
-// transposed (`acts`, the layout of mlp_f32_train.hip) and its sign bits (`bits`) for the backward pass.
+// as a record of blocked hi/lo words (`acts`, mlp_x3_common.h; row map of mlp_f32_train.hip) and its sign bits (`bits`) for
+// the backward pass.
 template <bool DEPTH_HEAD, int MODE, int PFD>
 __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_fwd_kernel(const float *__restrict__ feat,
                                                                       const char *__restrict__ packed,
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_fwd_kernel(const floa
             if (MODE == 1 && record) {  // the input columns, transposed, are operands of the weight gradients too
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    __builtin_nontemporal_store(a[c], acts + (size_t)(2432 + 16 * g + 4 * h + c) * ld + m);
-                    __builtin_nontemporal_store(b[c], acts + (size_t)(2432 + 16 * g + 8 + 4 * h + c) * ld + m);
+                    __builtin_nontemporal_store(x3_word(a[c]), (unsigned *)acts + x3_rec_index(2432 + 16 * g + 4 * h + c, m));
+                    __builtin_nontemporal_store(x3_word(b[c]), (unsigned *)acts + x3_rec_index(2432 + 16 * g + 8 + 4 * h + c, m));
                 }
             }
         }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_fwd_kernel(const floa
 #endif
 // vmcnt retires in order: the staging ring must also cover the acknowledgement of the activation stores
 
-// The training forward: also writes acts [2560, ld] (fp32, [feature][sample], row map of mlp_f32_train.hip) and
+// The training forward: also writes acts (2560 rows x ld samples, blocked hi/lo words; row map of mlp_f32_train.hip) and
 // bits [160, ld] (u16: word (tile * 2 + lane half) of a sample holds the signs of that lane's 16 values of the tile).
 DDN_EXPORT int ddnerf_mlp_x3_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts,
                                            void *bits, long M, long ld, ddnerf_stream_t stream) {

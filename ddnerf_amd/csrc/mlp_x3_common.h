@@ -140,22 +140,39 @@ __device__ __forceinline__ constexpr int x3_tile_row(int r, int h) { return (r &
 #define X3_STORE(v, p) __builtin_nontemporal_store(v, p)  // streaming data must not evict the weight images from L2
 #endif
 
-// Addresses are split into a uniform part (row of the tile x ld: scalar registers) and a per-lane 32-bit element offset
-// fixed for the whole kernel, so that every tile store / sign-word access is one saddr-form instruction -- computing
-// row * ld + col per lane in 64-bit VALU arithmetic had doubled the kernel's VALU instruction count.
+// Records of the x3 training tier (`acts` of the forward, `deltas` of the backward pass): "blocked hi/lo words".  Element
+// (row, sample m) is ONE 32-bit word (bf16 hi << 16) | bf16 lo -- hi = bf16(x), lo = bf16(x - hi), the split the kernels make
+// for their own next layer anyway -- at word index ((m >> 4) * X3_ACT_ROWS + row) * 16 + (m & 15): 16-sample blocks, inside a
+// block the rows back to back, 64 bytes each.  The weight-gradient kernel (mlp_x3_wgrad_packed.hip) streams a job's rows of a
+// block as ONE contiguous run straight into LDS; with the [row][sample] fp32 layout of the fp32 tier every row of a tile
+// is in another 2 MiB page, which held that kernel's reads to 2.4 TB/s (4.7 TB/s blocked) -- and the stores here scattered
+// the same way.
+#define X3_ACT_ROWS 2560
+__device__ __forceinline__ size_t x3_rec_index(int row, long m) { return ((size_t)(m >> 4) * X3_ACT_ROWS + row) * 16 + (m & 15); }
+__device__ __forceinline__ unsigned x3_word(float x) {
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    return ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | __builtin_bit_cast(unsigned short, lo);
+}
+// Addresses are split into a uniform part (the wave's 32 samples = two blocks, and the row of the tile: scalar registers)
+// and a per-lane 32-bit element offset fixed for the whole kernel, so that every tile store / sign-word access is one
+// saddr-form instruction -- computing the index per lane in 64-bit VALU arithmetic had doubled the kernel's VALU
+// instruction count.
 struct X3TileIO {
-    float *out;
+    unsigned *out;      // the record, advanced to the wave's first block
     unsigned short *bits_out;
     const unsigned short *bits_in;
-    size_t ld;
-    unsigned lane_f32;  // 4 h ld + col: element offset of this lane inside a tile's first row group (tile rows are
-                        // (r & 3) + 8 (r >> 2) + 4 h: the lane half selects rows +4)
+    size_t ld;          // of the sign words ([tile pair rows][sample])
+    unsigned lane_w;    // ((m >> 4) & 1) X3_ACT_ROWS 16 + 64 h + (m & 15): word offset of this lane inside a tile's first row group
+                        // (tile rows are (r & 3) + 8 (r >> 2) + 4 h: the lane half selects rows +4)
     unsigned lane_u16;  // h ld + col: this lane's sign word inside a tile's pair of word rows
     int row0;           // row of the layer's block 0 in `out` (a multiple of 32)
 };
 __device__ __forceinline__ X3TileIO x3_tile_io(float *out, unsigned short *bits_out, const unsigned short *bits_in, long ld,
                                                long col, int h, int row0) {
-    return X3TileIO{out, bits_out, bits_in, (size_t)ld, (unsigned)(4 * h * ld + col), (unsigned)(h * ld + col), row0};
+    const int m0 = __builtin_amdgcn_readfirstlane((int)(col & ~31L));  // a wave owns 32 consecutive samples
+    return X3TileIO{(unsigned *)out + (size_t)(m0 >> 4) * X3_ACT_ROWS * 16, bits_out, bits_in, (size_t)ld,
+                    (unsigned)(((col >> 4) & 1) * X3_ACT_ROWS * 16 + 64 * h + (col & 15)), (unsigned)(h * ld + col), row0};
 }
 
 // One stage: NBLK 32-row slices out of LDS buffer `cur`.  The statement order IS the schedule: a 32x32x16 MFMA occupies
@@ -233,12 +250,6 @@ __device__ __forceinline__ void x3_stage_compute(const char *__restrict__ cur, c
                 x0 = __builtin_bit_cast(float, __builtin_bit_cast(int, x0) & ((w << (31 - 2 * u)) >> 31));
                 x1 = __builtin_bit_cast(float, __builtin_bit_cast(int, x1) & ((w << (30 - 2 * u)) >> 31));
             }
-            if constexpr (MODE != 0) {
-                // uniform tile base + one of 16 uniform row offsets (common subexpressions across all tiles) + the lane part
-                float *tile = io.out + (size_t)(io.row0 + 32 * (B0 + pb)) * io.ld;
-                X3_STORE(x0, tile + (size_t)x3_tile_row(2 * u, 0) * io.ld + io.lane_f32);
-                X3_STORE(x1, tile + (size_t)x3_tile_row(2 * u + 1, 0) * io.ld + io.lane_f32);
-            }
             if constexpr (MODE == 1) {
                 // value > 0 <=> its bit pattern >= 1 (the values are >= +0 after the ReLU; layers without one never read
                 // their sign words): min(bits, 1) is the sign bit, one shift-or files it
@@ -250,6 +261,13 @@ __device__ __forceinline__ void x3_stage_compute(const char *__restrict__ cur, c
             }
             unsigned hw, lw;
             split_pair(x0, x1, hw, lw);
+            if constexpr (MODE != 0) {
+                // the record keeps the split: word = (hi << 16) | lo, one v_perm_b32 per value.  Uniform tile base + one of 16
+                // uniform row offsets (common subexpressions across all tiles) + the lane part
+                unsigned *tile = io.out + (size_t)(io.row0 + 32 * (B0 + pb)) * 16;
+                X3_STORE(__builtin_amdgcn_perm(hw, lw, 0x05040100u), tile + x3_tile_row(2 * u, 0) * 16 + io.lane_w);
+                X3_STORE(__builtin_amdgcn_perm(hw, lw, 0x07060302u), tile + x3_tile_row(2 * u + 1, 0) * 16 + io.lane_w);
+            }
             // registers 0..7 are k-step 2(B0+pb), 8..15 the next one; pair u&3 of that fragment
             u32x4 wh = __builtin_bit_cast(u32x4, Hnh[2 * (B0 + pb) + u / 4]);
             u32x4 wl = __builtin_bit_cast(u32x4, Hnl[2 * (B0 + pb) + u / 4]);

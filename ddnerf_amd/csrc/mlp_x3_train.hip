@@ -2,7 +2,7 @@
 // operand splits (mlp_x3.hip), mirroring mlp_f32_train.hip's fp32 pass:
 //     delta_l^T = (W_{l+1}^T delta_{l+1}^T) * relu'(h_l)
 // The accumulator tile of one step is re-packed into the hi/lo B files of the next, deltas never leave registers between
-// layers; every delta tile is also stored transposed into `deltas` (fp32, the operand layout of the weight-gradient
+// layers; every delta tile is also stored into `deltas` (blocked hi/lo words, mlp_x3_common.h: the operand of the weight-gradient
 // kernels).  relu' comes from the sign words the training forward recorded (2 bytes per lane per tile instead of the
 // 64-byte fp32 tile: the pass then writes 5.4 GB per fine launch and reads almost nothing).
 // Steps (K = rows of the incoming delta, NB = 32-row blocks of the outgoing one), as in mlp_f32_train.hip:
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(X3_WG_THREADS, 1) void mlp_x3_bwd_data_kernel(const
         split_quad(z, z, Xh[1], Xl[1]);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            __builtin_nontemporal_store(r < 4 ? a[r & 3] : 0.0f, deltas + (size_t)(ROW_X + x3_tile_row(r, h)) * ld + m);
+            __builtin_nontemporal_store(r < 4 ? x3_word(a[r & 3]) : 0u, (unsigned *)deltas + x3_rec_index(ROW_X + x3_tile_row(r, h), m));
     }
     auto io = [&](int row0) { return x3_tile_io(deltas, nullptr, bits, ld, m, h, row0); };
     using PL = X3BwdPlan;

@@ -1,0 +1,243 @@
+// K2b'' weight gradients of the "x3" training tier on PRE-SPLIT operands.
+//
+// Same contraction and the same three-MFMA product as mlp_x3_wgrad.hip (dW[out][in] = sum_s delta^T[out][s] act^T[in][s],
+// a*b = lo_a hi_b + hi_a lo_b + hi_a hi_b on v_mfma_f32_32x32x16_bf16), but the operands arrive as the words the x3 training
+// kernels now record: every element of `deltas` / `acts` is one 32-bit word  (bf16 hi << 16) | bf16 lo,  hi = bf16(x),
+// lo = bf16(x - hi) -- the split those kernels compute anyway for their own next layer.  That removes what bounded the
+// fp32-operand kernel (one 32-sample tile in flight per workgroup, held in registers, split in VALU, parked in LDS: 3.7 TB/s):
+//   * the words go global -> LDS by LDS-DMA (global_load_lds_dwordx4), no registers, no split, no park pass;
+//   * LDS is a ring of 16-sample slots (one k = 16 MFMA step of all NOP + NIN rows, 64 B per row); while slot u feeds the
+//     MFMAs the transfers of slots u+1 .. u+NS-2 are in flight and slot u+NS-1 is issued: one bare s_barrier per slot;
+//   * a fragment is two ds_read_b128 (8 words of a row) and 8 v_perm_b32 (hi pairs, lo pairs).
+// LDS layout of a slot: row r at 64 r, its four 16-byte chunks XOR-swizzled with (r >> 2) & 3 -- the 16 lanes of a b128 read
+// phase (16 consecutive rows, same chunk) then cover all 64 banks.  A transfer instruction moves 16 rows x 64 B; the lane ->
+// LDS position map of LDS-DMA is fixed (lane * 16 B), so the swizzle is applied to the SOURCE chunk each lane fetches.
+// The two 64-byte halves of a 128-byte HBM line are fetched by consecutive slots, a slot period apart: the second is an L2 hit.
+//
+// Split-K partition, MFMA order and the slab reduction are those of mlp_x3_wgrad.hip, so for operands that are the exact
+// splits of fp32 matrices the weight gradients are bit-identical to that kernel's; the bias sums add hi + lo per element
+// (relative 2^-17 per term instead of exact).
+#include "mlp_f32_common.h"
+#include "wgrad_reduce.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define XP_ROWS 2560                // rows of a record (X3_ACT_ROWS, mlp_x3_common.h)
+#define XP_STEP (XP_ROWS * 64)      // bytes from one 16-sample block to the next
+#define XP_TILE 32  // samples per split-K granule (two ring slots), as in mlp_x3_wgrad.hip
+
+__device__ __forceinline__ unsigned xp_lds_addr(const void *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
+}
+// 8 packed words (k = 0..7 of one row) -> the bf16x8 of their hi halves and of their lo halves
+__device__ __forceinline__ void xp_unpack(const u32x4 w0, const u32x4 w1, bf16x8 &hi, bf16x8 &lo) {
+    const u32x4 h = {__builtin_amdgcn_perm(w0.y, w0.x, 0x07060302u), __builtin_amdgcn_perm(w0.w, w0.z, 0x07060302u),
+                     __builtin_amdgcn_perm(w1.y, w1.x, 0x07060302u), __builtin_amdgcn_perm(w1.w, w1.z, 0x07060302u)};
+    const u32x4 l = {__builtin_amdgcn_perm(w0.y, w0.x, 0x05040100u), __builtin_amdgcn_perm(w0.w, w0.z, 0x05040100u),
+                     __builtin_amdgcn_perm(w1.y, w1.x, 0x05040100u), __builtin_amdgcn_perm(w1.w, w1.z, 0x05040100u)};
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+__device__ __forceinline__ float xp_value(unsigned w) {
+    return __builtin_bit_cast(float, w & 0xffff0000u) + __builtin_bit_cast(float, w << 16);
+}
+
+template <int ROWS> constexpr int xp_nslot() { return ROWS * 64 * 8 <= 160 * 1024 ? 8 : 4; }
+
+template <int RT, int CT, int RG, int CG, bool BIAS>
+__global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned *__restrict__ dT, const unsigned *__restrict__ aT,
+                                                                  long M, long ld, int tiles_per_wg,
+                                                                  float *__restrict__ slabs, float *__restrict__ bias_slabs) {
+    constexpr int NOP = 32 * RT * RG, NIN = 32 * CT * CG, NW = RG * CG, THREADS = 64 * NW, ROWS = NOP + NIN;
+    constexpr int NI = ROWS / 16, IPW = (NI + NW - 1) / NW;  // transfer instructions per slot / per wave (surplus ones repeat the last)
+    constexpr int SLOT = ROWS * 64, NS = xp_nslot<ROWS>();
+    constexpr int NBI = NOP * 4, MAXB = (NBI + THREADS - 1) / THREADS;  // bias items (row, chunk) per slot / per thread
+    static_assert((NS - 2) * IPW <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int rg = wave % RG, cg = wave / RG;
+    const long tile0 = (long)blockIdx.x * tiles_per_wg;
+    const long ntiles_total = (M + XP_TILE - 1) / XP_TILE;
+    const int ntiles = (int)max(0L, min((long)tiles_per_wg, ntiles_total - tile0));
+    const int nht = 2 * ntiles;
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.0f;
+    float bsum[MAXB];
+#pragma unroll
+    for (int r = 0; r < MAXB; ++r) bsum[r] = 0.0f;
+
+    // transfer i of this wave: rows 16k .. 16k+15 of the slot, k = wave + NW i (clamped: a surplus transfer repeats the last
+    // one, same data to the same place, so that every wave issues IPW per slot and one vmcnt value certifies a slot)
+    unsigned voff[IPW], ldst[IPW];
+    const char *src[IPW];
+    const unsigned lds0 = xp_lds_addr(lds_raw);
+#pragma unroll
+    for (int t = 0; t < IPW; ++t) {
+        const int k = min(wave + NW * t, NI - 1);                      // (uniform)
+        const int row = 16 * k + (lane >> 2);
+        const int q = (lane & 3) ^ ((lane >> 4) & 3);                  // source chunk of LDS chunk (lane & 3): (row >> 2) & 3 swizzle
+        const bool in_d = 16 * k < NOP;                                // (uniform; NOP is a multiple of 16)
+        voff[t] = (unsigned)((in_d ? row : row - NOP) * 64 + q * 16);
+        src[t] = (const char *)(in_d ? dT : aT) + (size_t)tile0 * 2 * XP_STEP;
+        ldst[t] = lds0 + k * 1024;
+    }
+    // ragged tail: ld is a multiple of 128 >= M, pad columns of `deltas` are zero words, those of `acts` finite
+    auto issue = [&](int u) {
+        const int uc = min(u, nht - 1);  // past the end: harmless repeats into a slot nobody reads again
+        const unsigned slot = (unsigned)(u % NS) * SLOT;
+#pragma unroll
+        for (int t = 0; t < IPW; ++t)
+            asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(src[t] + (size_t)uc * XP_STEP), "{m0}"(ldst[t] + slot)
+                         : "memory");
+    };
+    const int x = (i >> 2) & 3;
+    const unsigned o0 = i * 64 + (((2 * h) ^ x) * 16), o1 = o0 ^ 16;
+
+    if (nht > 0) {
+#pragma unroll
+        for (int u = 0; u < NS - 1; ++u) issue(u);
+    }
+    for (int u = 0; u < nht; ++u) {
+        // slot u has landed (this wave's share: all but the transfers of the NS-2 slots issued after it), for every wave; and
+        // every wave is done with slot u-1, whose buffer the next transfers overwrite
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(u + NS - 1);
+        const char *sb = lds_raw + (size_t)(u % NS) * SLOT;
+        bf16x8 ah[RT], al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const char *p = sb + (rg * RT + rt) * 32 * 64;
+            xp_unpack(*(const u32x4 *)(p + o0), *(const u32x4 *)(p + o1), ah[rt], al[rt]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const char *p = sb + (NOP + (cg * CT + ct) * 32) * 64;
+            bf16x8 bh, bl;
+            xp_unpack(*(const u32x4 *)(p + o0), *(const u32x4 *)(p + o1), bh, bl);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                // small terms first
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][ct], 0, 0, 0);
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][ct], 0, 0, 0);
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][ct], 0, 0, 0);
+            }
+        }
+        if (BIAS) {
+#pragma unroll
+            for (int r = 0; r < MAXB; ++r) {
+                const int idx = r * THREADS + tid;
+                if ((r + 1) * THREADS <= NBI || idx < NBI) {
+                    const u32x4 w = *(const u32x4 *)(sb + idx * 16);
+                    bsum[r] += (xp_value(w.x) + xp_value(w.y)) + (xp_value(w.z) + xp_value(w.w));
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus transfers of the last slots
+
+    float *slab = slabs + (size_t)blockIdx.x * NOP * NIN;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                slab[(size_t)((rg * RT + rt) * 32 + tile_row(r, h)) * NIN + (cg * CT + ct) * 32 + i] = acc[rt][ct][r];
+    if (BIAS) {
+        // item (row, chunk) is owned by the same thread in every slot; the 4 chunks of a row sit in 4 adjacent lanes
+#pragma unroll
+        for (int r = 0; r < MAXB; ++r) {
+            const int idx = r * THREADS + tid, row = idx >> 2;
+            float s = bsum[r];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if ((idx & 3) == 0 && row < NOP) bias_slabs[(size_t)blockIdx.x * NOP + row] = s;
+        }
+    }
+}
+
+static int n_out_pad_of(int n_out) { return n_out > 128 ? 256 : (n_out > 32 ? 128 : 32); }
+
+// Same contract as ddnerf_mlp_x3_wgrad (mlp_x3_wgrad.hip) on the x3 tier's records: `deltas` and `acts` are blocked hi/lo-word
+// records of 2560 rows x ld samples (ld / 16 blocks), as ddnerf_mlp_x3_forward_train / ddnerf_mlp_x3_backward_data write them and as
+// ddnerf_mlp_x3_split produces them from fp32 matrices.
+DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in,
+                                          int n_in_used, long M, long ld, float *dst, int dst_ld, int dst_col0,
+                                          float *dst_bias, float *workspace, ddnerf_stream_t stream) {
+    DDN_REQUIRE(deltas && acts && dst && workspace, DDNERF_E_ARG);
+    DDN_REQUIRE(M > 0 && n_out > 0 && n_out <= 256 && n_in_used > 0 && n_in_used <= n_in, DDNERF_E_ARG);
+    DDN_REQUIRE(n_in == 32 || n_in == 96 || n_in == 128 || n_in == 256, DDNERF_E_RANGE);
+    DDN_REQUIRE(ld % 32 == 0 && ld >= M, DDNERF_E_RANGE);  // the records hold ld / 16 whole blocks
+    DDN_REQUIRE(drow0 >= 0 && arow0 >= 0 && drow0 + n_out_pad_of(n_out) <= XP_ROWS && arow0 + n_in <= XP_ROWS, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(deltas, 16) && ddn_aligned(acts, 16), DDNERF_E_ALIGN);
+    hipStream_t st = (hipStream_t)stream;
+    const int n_out_pad = n_out_pad_of(n_out);
+    const long ntiles = (M + XP_TILE - 1) / XP_TILE;
+    const int nwg = (int)(ntiles < 256 ? ntiles : 256);
+    const int tiles_per_wg = (int)((ntiles + nwg - 1) / nwg);
+    const unsigned *dT = (const unsigned *)deltas + (size_t)drow0 * 16, *aT = (const unsigned *)acts + (size_t)arow0 * 16;
+    float *slabs = workspace;
+    const size_t slab_stride = (size_t)n_out_pad * n_in;
+    float *bias_slabs = dst_bias ? workspace + (size_t)nwg * slab_stride : nullptr;
+#define LAUNCH(RT, CT, RG, CG)                                                                                          \
+    do {                                                                                                                \
+        constexpr int ROWS_ = 32 * RT * RG + 32 * CT * CG;                                                              \
+        const size_t lds = (size_t)ROWS_ * 64 * xp_nslot<ROWS_>();                                                      \
+        if (bias_slabs)                                                                                                 \
+            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, true>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, M, ld, \
+                               tiles_per_wg, slabs, bias_slabs);                                                        \
+        else                                                                                                            \
+            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, false>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, M, ld, \
+                               tiles_per_wg, slabs, bias_slabs);                                                        \
+    } while (0)
+    if (n_out_pad == 256) {
+        if (n_in == 256) LAUNCH(2, 4, 4, 2); else if (n_in == 128) LAUNCH(1, 4, 8, 1); else if (n_in == 96) LAUNCH(1, 3, 8, 1); else LAUNCH(1, 1, 8, 1);
+    } else if (n_out_pad == 128) {
+        if (n_in == 256) LAUNCH(1, 4, 4, 2); else if (n_in == 128) LAUNCH(1, 2, 4, 2); else if (n_in == 96) LAUNCH(1, 3, 4, 1); else LAUNCH(1, 1, 4, 1);
+    } else {
+        if (n_in == 256) LAUNCH(1, 2, 1, 4); else if (n_in == 128) LAUNCH(1, 1, 1, 4); else if (n_in == 96) LAUNCH(1, 3, 1, 1); else LAUNCH(1, 1, 1, 1);
+    }
+#undef LAUNCH
+    const int total = n_out * n_in_used;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, slabs, nwg, slab_stride, n_in, 0, 0,
+                       n_out, n_in_used, dst, dst_ld, dst_col0);
+    if (dst_bias)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64), dim3(256), 0, st, bias_slabs, nwg,
+                           (size_t)n_out_pad, 1, 0, 0, n_out, 1, dst_bias, 1, 0);
+    return ddn_launch_status();
+}
+
+// fp32 [rows][ld] ([feature][sample]) -> rows row0 .. row0 + rows - 1 of a blocked hi/lo-word record (mlp_x3_common.h): the
+// operand format of ddnerf_mlp_x3_wgrad_packed, for callers that hold plain fp32 matrices
+__global__ __launch_bounds__(256) void x3_split_kernel(const float *__restrict__ x, long ld, int row0, unsigned *__restrict__ rec) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;  // quad of samples
+    const int row = blockIdx.y;
+    if (4 * q >= ld) return;
+    const f32x4 v = *(const f32x4 *)(x + (size_t)row * ld + 4 * q);
+    u32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const __bf16 hi = (__bf16)v[c];
+        const __bf16 lo = (__bf16)(v[c] - (float)hi);
+        o[c] = ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | __builtin_bit_cast(unsigned short, lo);
+    }
+    *(u32x4 *)(rec + (((size_t)(q >> 2) * XP_ROWS + row0 + row) * 16 + 4 * (q & 3))) = o;
+}
+DDN_EXPORT int ddnerf_mlp_x3_split(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream) {
+    DDN_REQUIRE(x && record, DDNERF_E_ARG);
+    DDN_REQUIRE(rows > 0 && row0 >= 0 && row0 + rows <= XP_ROWS && ld > 0 && ld % 16 == 0, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(x, 16) && ddn_aligned(record, 16), DDNERF_E_ALIGN);
+    hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((ld / 4 + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, ld,
+                       row0, (unsigned *)record);
+    return ddn_launch_status();
+}

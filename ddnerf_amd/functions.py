@@ -43,8 +43,8 @@ def _forward_kernel(feat, net):
 
 class _MLPFunction(torch.autograd.Function):
     """training forward + hand-written backward of one network.  `mlp_dtype` "fp32" runs the exact fp32-MFMA kernels;
-    "x3" the split-precision bf16-MFMA kernels (same accuracy class, ~2.5x faster); weight gradients follow
-    ops.WGRAD_MODE in both."""
+    "x3" the split-precision bf16-MFMA kernels (same accuracy class, ~2.5x faster), which record their activations and
+    deltas pre-split for the packed-operand weight-gradient kernel; the fp32 tier's weight gradients follow ops.WGRAD_MODE."""
 
     @staticmethod
     def forward(ctx, feat, net, *params):
@@ -75,7 +75,8 @@ class _MLPFunction(torch.autograd.Function):
             feat, acts = ctx.saved_tensors
             packed_t = _cached_pack(net, "fp32_t", ops.mlp_f32_pack_t)
             deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head)
-        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0])
+        # (the x3 kernels record hi/lo words for the packed-operand weight-gradient kernel; DDNERF_WGRAD=f32 cannot read them)
+        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3p" if ctx.x3 else None)
         net.last_flat_grad = flat_g  # the data-parallel bucket (ddnerf_amd.dist) reduces this buffer
         reducer = getattr(net, "grad_reducer", None)
         if reducer is not None:

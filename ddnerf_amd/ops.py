@@ -357,7 +357,8 @@ def mlp_x3_pack_t(params_flat, depth_head):
 
 
 def mlp_x3_forward_train(feat, packed, depth_head):
-    """x3 forward that records activations: -> raw [M,4|6], acts [2560, ld] fp32, bits [160, ld] uint16 (sign words)"""
+    """x3 forward that records activations: -> raw [M,4|6], acts = a [2560, ld] record of blocked hi/lo words (x3_unsplit gives
+    the fp32 [feature][sample] matrix), bits [160, ld] uint16 (sign words)"""
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
     ld = (M + 127) // 128 * 128
@@ -377,6 +378,7 @@ def mlp_x3_forward_train(feat, packed, depth_head):
 
 
 def mlp_x3_backward_data(g_raw, packed_t, bits, depth_head):
+    """-> deltas: a [2560, ld] record of blocked hi/lo words, like mlp_x3_forward_train's acts"""
     g_raw = _f32c(g_raw, "g_raw")
     M = g_raw.shape[0]
     ld = bits.shape[1]
@@ -412,18 +414,40 @@ def ndc_rays(H, W, focal, origins, directions, near=1.0):
 
 # weight-gradient arithmetic: "x3" = bf16 matrix cores with exact hi/lo operand splits (3 MFMAs per product, ~2^-16
 # relative product error, HBM-bound); "f32" = the fp32 matrix cores (exact fp32 products, MFMA-bound, 3x slower)
+# "x3p" = the same three-MFMA product on operands that already hold hi/lo words (what the x3 training kernels record)
 WGRAD_MODE = os.environ.get("DDNERF_WGRAD", "x3")
+_WGRAD_FN = {"x3": "ddnerf_mlp_x3_wgrad", "f32": "ddnerf_mlp_f32_wgrad", "x3p": "ddnerf_mlp_x3_wgrad_packed"}
 
 
-def mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, dst, dst_ld, dst_col0, dst_bias, workspace):
+def x3_split(x):
+    """fp32 [2560, ld] ([feature][sample]) -> the x3 training tier's record of the same matrix: blocked hi/lo words
+    (include/ddnerf_hip.h, ddnerf_mlp_x3_wgrad_packed), in a float32-typed tensor of the same shape (bit patterns, not values)"""
+    x = _f32c(x, "x")
+    assert x.shape[0] == ACT_ROWS and x.shape[1] % 16 == 0
+    w = torch.empty_like(x)
+    _lib.check(_lib.lib().ddnerf_mlp_x3_split(_ptr(x), x.shape[0], x.shape[1], 0, _ptr(w), _stream()), "ddnerf_mlp_x3_split")
+    return w
+
+
+def x3_unsplit(rec):
+    """a record of the x3 training tier -> fp32 [2560, ld] values hi + lo (differs from the recorded value by <= 2^-17 relative)"""
+    ld = rec.shape[1]
+    i = rec.view(torch.int32).view(ld // 16, ACT_ROWS, 16).permute(1, 0, 2).reshape(ACT_ROWS, ld)
+    return (i & -65536).view(torch.float32) + (i << 16).view(torch.float32)
+
+
+def mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, dst, dst_ld, dst_col0, dst_bias, workspace,
+                      mode=None):
     """dst[r*dst_ld + dst_col0 + c] = sum_s deltas[drow0+r][s] * acts[arow0+c][s]; dst_bias[r] = sum_s deltas[drow0+r][s]"""
-    fn = _lib.lib().ddnerf_mlp_x3_wgrad if WGRAD_MODE == "x3" else _lib.lib().ddnerf_mlp_f32_wgrad
+    mode = mode or WGRAD_MODE
+    fn = getattr(_lib.lib(), _WGRAD_FN[mode])
     _lib.check(fn(_ptr(deltas), drow0, n_out, _ptr(acts), arow0, n_in, n_in_used, M, deltas.shape[1], _ptr(dst), dst_ld,
-                  dst_col0, _ptr(dst_bias), _ptr(workspace), _stream()), "ddnerf_mlp_%s_wgrad" % WGRAD_MODE)
+                  dst_col0, _ptr(dst_bias), _ptr(workspace), _stream()), _WGRAD_FN[mode])
 
 
-def mlp_f32_weight_grads(net, acts, deltas, M):
-    """all parameter gradients of one network -> (flat gradient buffer in registration order, per-parameter views)"""
+def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
+    """all parameter gradients of one network -> (flat gradient buffer in registration order, per-parameter views).
+    mode "x3p": acts / deltas are the x3 training kernels' records (blocked hi/lo words)."""
     params = list(net.parameters())
     flat_g = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=acts.device)
     off, gv, views = 0, {}, []
@@ -433,7 +457,7 @@ def mlp_f32_weight_grads(net, acts, deltas, M):
         views.append(v)
         off += p.numel()
     ws = torch.empty(_lib.lib().ddnerf_mlp_f32_wgrad_workspace_floats(M), dtype=torch.float32, device=acts.device)
-    job = lambda *a: mlp_f32_wgrad_job(deltas, a[0], a[1], acts, a[2], a[3], a[4], M, a[5], a[6], a[7], a[8], ws)
+    job = lambda *a: mlp_f32_wgrad_job(deltas, a[0], a[1], acts, a[2], a[3], a[4], M, a[5], a[6], a[7], a[8], ws, mode=mode)
     for l in range(8):
         w, b = gv["layers_xyz.%d.weight" % l], gv["layers_xyz.%d.bias" % l]
         if l == 0:

@@ -101,10 +101,11 @@ int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head,
 /* x3 training kernels (same network, same accuracy class): the forward that records what the backward needs, the W^T
  * images, and the fused backward-data pass -- drop-ins for ddnerf_mlp_f32_forward_train / _pack_t / _backward_data.
  *   packed: the training forward's own weight image (ddnerf_mlp_x3_train_pack; not the inference kernel's)
- *   acts  [ddnerf_mlp_act_rows(), ld] fp32, [feature][sample] (row map as for the fp32 kernels); ld = M rounded up to 128
+ *   acts  a RECORD of ddnerf_mlp_act_rows() rows x ld samples (row map as for the fp32 kernels; ld = M rounded up to 128) in
+ *         "blocked hi/lo words" -- see ddnerf_mlp_x3_wgrad_packed, the kernel that reads it -- NOT an fp32 matrix
  *   bits  [160, ld] uint16: word (tile*2 + lane_half) of a sample = signs of that lane's 16 values of 32-row tile `tile`
  *         (relu' for the backward pass; 2 bytes instead of the 64-byte fp32 tile)
- *   deltas [ddnerf_mlp_act_rows(), ld] fp32: every layer's pre-activation gradient, rows as in `acts`; rows 2432.. = d(raw) */
+ *   deltas a record like `acts`: every layer's pre-activation gradient, rows as in `acts`; rows 2432.. = d(raw) */
 size_t ddnerf_mlp_x3_train_packed_bytes(int depth_head);
 int ddnerf_mlp_x3_train_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_x3_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts, void *bits,
@@ -227,6 +228,19 @@ int ddnerf_mlp_f32_wgrad(const float *deltas, int drow0, int n_out, const float 
 int ddnerf_mlp_x3_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,
                          long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
                          ddnerf_stream_t stream);
+/* The x3 training tier's own weight-gradient kernel: same contract, but `deltas` and `acts` are the RECORDS that
+ * ddnerf_mlp_x3_forward_train and ddnerf_mlp_x3_backward_data write: 2560 rows x ld samples of "blocked hi/lo words".  Element
+ * (row, sample m) is one 32-bit word (bf16 hi << 16) | bf16 lo, hi = bf16(x), lo = bf16(x - hi) (the split those kernels
+ * compute for their own next layer anyway), at word index ((m >> 4) * 2560 + row) * 16 + (m & 15): 16-sample blocks, the
+ * rows of a block back to back.  A job's rows of a block are one contiguous run that travels HBM -> LDS by LDS-DMA and feeds
+ * the MFMAs without a split pass (4.7 TB/s where the [row][sample] fp32 operands of ddnerf_mlp_x3_wgrad reach 3.3).  ld must
+ * be a multiple of 32.  Weight gradients are bit-identical to ddnerf_mlp_x3_wgrad on the fp32 matrices the words were split
+ * from; bias sums add hi + lo (2^-17 relative per term). */
+int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
+                                long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
+                                ddnerf_stream_t stream);
+/* fp32 [rows][ld] ([feature][sample], ld a multiple of 16) -> rows row0 .. row0 + rows - 1 of such a record. */
+int ddnerf_mlp_x3_split(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -302,16 +302,18 @@ def test_weight_gradient_kernels_at_full_size(ops):
     acts = torch.randn(2560, M, device="cuda", generator=g)
     deltas = torch.randn(2560, M, device="cuda", generator=g) * 1e-3
     ws = torch.empty(ops._lib.lib().ddnerf_mlp_f32_wgrad_workspace_floats(M), dtype=torch.float32, device="cuda")
+    # the x3 tier's own kernel reads records of blocked hi/lo words (what its forward / backward kernels write)
+    rec_a, rec_d = ops.x3_split(acts), ops.x3_split(deltas)
+    assert float((ops.x3_unsplit(rec_a) - acts).abs().max()) <= 2.0 ** -16 * float(acts.abs().max())
     for drow0, n_out, arow0, n_in, used, col0, ld in ((512, 256, 256, 256, 256, 0, 256), (0, 256, 2432, 96, 96, 0, 96),
                                                       (1280, 256, 1024, 256, 256, 96, 352), (2432, 3, 2304, 128, 128, 0, 128)):
         outs = {}
-        for mode in ("x3", "f32"):
-            ops.WGRAD_MODE = mode
+        for mode in ("x3", "f32", "x3p"):
             w = torch.zeros(n_out, ld, device="cuda")
             b = torch.zeros(n_out, device="cuda")
-            ops.mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, used, M, w, ld, col0, b, ws)
+            D, A = (rec_d, rec_a) if mode == "x3p" else (deltas, acts)
+            ops.mlp_f32_wgrad_job(D, drow0, n_out, A, arow0, n_in, used, M, w, ld, col0, b, ws, mode=mode)
             outs[mode] = (w.clone(), b.clone())
-        ops.WGRAD_MODE = "x3"
         ref_w = deltas[drow0:drow0 + n_out] @ acts[arow0:arow0 + used].T
         ref_b = deltas[drow0:drow0 + n_out].double().sum(1).float()
         scale = float(ref_w.abs().max())
@@ -321,6 +323,7 @@ def test_weight_gradient_kernels_at_full_size(ops):
             if col0:
                 assert float(w[:, :col0].abs().max()) == 0.0          # columns outside the job are not touched
         assert float((outs["x3"][0] - outs["f32"][0]).abs().max()) <= 5e-5 * scale
+        assert torch.equal(outs["x3"][0], outs["x3p"][0])   # same splits, same partition, same MFMA order: bit-identical
 
 
 def test_training_kernels_at_full_size(ops):
@@ -339,13 +342,15 @@ def test_training_kernels_at_full_size(ops):
     raw_x, acts_x, bits = ops.mlp_x3_forward_train(feat, ops.mlp_x3_train_pack(flat, depth), depth)
     assert float((raw_f - raw_x).abs().max()) <= 2e-5 * float(raw_f.abs().max())
     rows = torch.cat([torch.arange(0, 2432, 37, device="cuda"), torch.arange(2432, 2555, device="cuda")])
-    a, b = acts_f[rows], acts_x[rows]
+    acts_xv = ops.x3_unsplit(acts_x)     # (the x3 kernels record blocked hi/lo words)
+    a, b = acts_f[rows], acts_xv[rows]
     assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
-    assert torch.equal(acts_f[2432:2555], acts_x[2432:2555])                      # the transposed input columns: exact copies
+    # the transposed input columns: the exact hi/lo split of the features
+    assert torch.equal(ops.x3_split(acts_f).view(torch.int32).view(-1, 2560, 16)[:, 2432:2555], acts_x.view(torch.int32).view(-1, 2560, 16)[:, 2432:2555])
     d_f = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_f, depth)
     d_x = ops.mlp_x3_backward_data(G, ops.mlp_x3_pack_t(flat, depth), bits, depth)
     rows = torch.cat([torch.arange(0, 2432, 41, device="cuda"), torch.arange(2432, 2438, device="cuda")])
-    a, b = d_f[rows], d_x[rows]
+    a, b = d_f[rows], ops.x3_unsplit(d_x)[rows]
     off = (a - b).abs() > 1e-4 * float(a.abs().max())
     assert float(off.float().mean()) <= 1e-4, float(off.float().mean())            # kink flips only (measured ~1e-5)
     assert float((a - b).norm()) <= 2e-3 * float(a.norm())
