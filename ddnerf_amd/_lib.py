@@ -25,8 +25,6 @@ _SIGS = {
     "ddnerf_mlp_x3_packed_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_x3_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_x3_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
-    "ddnerf_mlp_x3_train_packed_bytes": (C.c_size_t, [C.c_int]),
-    "ddnerf_mlp_x3_train_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_x3_forward_train": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_mlp_x3_packed_t_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_x3_pack_t": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),

@@ -27,17 +27,18 @@ SOURCES = {
     "mlp_x3_wgrad_packed.hip": [],
     # accumulators in arch VGPRs (the VALU re-pack reads them), B files in the accumulator half: see mlp_bf16.hip
     "mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-    "mlp_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     # (no SLP vectoriser: it packs the two subtractions of the hi / lo split into v_pk_add_f32, which costs more issue time
     # beside MFMAs than two v_sub_f32)
     "mlp_x3_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+    "mlp_x3_fwd_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     "mlp_x3_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }
 
 
 # kernels whose matrix instructions are inline asm: the compiler's assembly is scanned for dependent pairs that sit closer
 # than the wait states nobody pads (csrc/check_asm_hazards.py); a violation fails the build
-CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel"}
+CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel",
+           "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel"}
 
 
 def _compile_checked(cmd, src, obj, kernel, verbose):

@@ -1,4 +1,4 @@
-// Shared device helpers of the kernels on the bf16 matrix cores (mlp_bf16.hip, mlp_x3.hip).
+// Shared device helpers of the kernels on the bf16 matrix cores (mlp_bf16.hip, mlp_x3_fwd.hip, mlp_x3_fwd_train.hip, mlp_x3_train.hip).
 #pragma once
 #include <utility>
 

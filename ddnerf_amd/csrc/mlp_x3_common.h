@@ -1,6 +1,7 @@
-// Stage machinery shared by the x3 kernels (mlp_x3.hip: inference forward; mlp_x3_train.hip: the forward that records
-// activations and the fused backward-data pass).  See mlp_x3.hip for the arithmetic (exact hi/lo bf16 operand splits,
-// three MFMAs per product) and the formulation (transposed layers, activations chained through registers).
+// Stage machinery of the x3 backward-data kernel (mlp_x3_train.hip), on v_mfma_f32_32x32x16_bf16: exact hi/lo bf16 operand
+// splits, three MFMAs per product, transposed layers, tiles chained through registers, two LDS stage buffers.  (The forward
+// kernels moved to the 16x16x32 body of mlp_mfma16.inc: mlp_x3_fwd.hip, mlp_x3_fwd_train.hip; the MODE 0 / MODE 1 paths here are
+// what the backward pass shares with the forward formulation it was written beside.)
 #pragma once
 #include "mlp_bf16_common.h"
 

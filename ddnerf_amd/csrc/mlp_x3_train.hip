@@ -1,5 +1,5 @@
 // K2 ("x3") backward-data: ONE kernel chains d(raw) back through all layers on the bf16 matrix cores with exact hi/lo
-// operand splits (mlp_x3.hip), mirroring mlp_f32_train.hip's fp32 pass:
+// operand splits (mlp_x3_common.h), mirroring mlp_f32_train.hip's fp32 pass:
 //     delta_l^T = (W_{l+1}^T delta_{l+1}^T) * relu'(h_l)
 // The accumulator tile of one step is re-packed into the hi/lo B files of the next, deltas never leave registers between
 // layers; every delta tile is also stored into `deltas` (blocked hi/lo words, mlp_x3_common.h: the operand of the weight-gradient

@@ -51,8 +51,7 @@ class _MLPFunction(torch.autograd.Function):
         if net.mlp_dtype == "bf16":
             raise NotImplementedError("training runs on the fp32 / x3 MLP kernels; the plain bf16 kernel is inference-only")
         ctx.x3 = net.mlp_dtype == "x3"
-        # (the x3 training forward reads its own weight image: the inference kernel's is laid out for another MFMA shape)
-        packed = _cached_pack(net, "x3_train", ops.mlp_x3_train_pack) if ctx.x3 else _packed_weights(net)
+        packed = _packed_weights(net)
         if ctx.x3:
             raw, acts, bits = ops.mlp_x3_forward_train(feat, packed, net.depth_head)
             ctx.save_for_backward(feat, acts, bits)

@@ -126,15 +126,6 @@ def mlp_x3_pack(params_flat, depth_head):
     return packed
 
 
-def mlp_x3_train_pack(params_flat, depth_head):
-    """the weight image of the x3 TRAINING forward (mlp_x3_forward_train); the inference kernel has its own (mlp_x3_pack)"""
-    params_flat = _f32c(params_flat, "params")
-    nbytes = _lib.lib().ddnerf_mlp_x3_train_packed_bytes(int(depth_head))
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=params_flat.device)
-    _lib.check(_lib.lib().ddnerf_mlp_x3_train_pack(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()), "ddnerf_mlp_x3_train_pack")
-    return packed
-
-
 def mlp_x3_forward(feat, packed, depth_head):
     """the MLP on the bf16 matrix cores with exact hi/lo operand splits (fp32-class accuracy): feat fp32 [M,128] -> raw"""
     feat = _f32c(feat, "feat")

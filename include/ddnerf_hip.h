@@ -100,14 +100,12 @@ int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head,
 
 /* x3 training kernels (same network, same accuracy class): the forward that records what the backward needs, the W^T
  * images, and the fused backward-data pass -- drop-ins for ddnerf_mlp_f32_forward_train / _pack_t / _backward_data.
- *   packed: the training forward's own weight image (ddnerf_mlp_x3_train_pack; not the inference kernel's)
+ *   packed: the inference kernel's weight image (ddnerf_mlp_x3_pack): the training forward is the same kernel plus the records
  *   acts  a RECORD of ddnerf_mlp_act_rows() rows x ld samples (row map as for the fp32 kernels; ld = M rounded up to 128) in
  *         "blocked hi/lo words" -- see ddnerf_mlp_x3_wgrad_packed, the kernel that reads it -- NOT an fp32 matrix
- *   bits  [160, ld] uint16: word (tile*2 + lane_half) of a sample = signs of that lane's 16 values of 32-row tile `tile`
- *         (relu' for the backward pass; 2 bytes instead of the 64-byte fp32 tile)
+ *   bits  [160, ld] uint16 sign words (relu' for the backward pass, 1 bit instead of 4 bytes per value): bit r of word
+ *         bits[2 T + h][m] is set iff row 32 T + (r & 3) + 8 (r >> 2) + 4 h of `acts` is > 0 for sample m
  *   deltas a record like `acts`: every layer's pre-activation gradient, rows as in `acts`; rows 2432.. = d(raw) */
-size_t ddnerf_mlp_x3_train_packed_bytes(int depth_head);
-int ddnerf_mlp_x3_train_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_x3_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts, void *bits,
                                 long M, long ld, ddnerf_stream_t stream);
 size_t ddnerf_mlp_x3_packed_t_bytes(int depth_head);

@@ -339,7 +339,7 @@ def test_training_kernels_at_full_size(ops):
     feat[:, :123] = torch.rand(M, 123, device="cuda", generator=g) * 2 - 1
     G = torch.randn(M, 6, device="cuda", generator=g)
     raw_f, acts_f = ops.mlp_f32_forward_train(feat, ops.mlp_f32_pack(flat, depth), depth)
-    raw_x, acts_x, bits = ops.mlp_x3_forward_train(feat, ops.mlp_x3_train_pack(flat, depth), depth)
+    raw_x, acts_x, bits = ops.mlp_x3_forward_train(feat, ops.mlp_x3_pack(flat, depth), depth)
     assert float((raw_f - raw_x).abs().max()) <= 2e-5 * float(raw_f.abs().max())
     rows = torch.cat([torch.arange(0, 2432, 37, device="cuda"), torch.arange(2432, 2555, device="cuda")])
     acts_xv = ops.x3_unsplit(acts_x)     # (the x3 kernels record blocked hi/lo words)
