@@ -208,12 +208,10 @@ DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_o
         if (n_in == 256) LAUNCH(1, 2, 1, 4); else if (n_in == 128) LAUNCH(1, 1, 1, 4); else if (n_in == 96) LAUNCH(1, 3, 1, 1); else LAUNCH(1, 1, 1, 1);
     }
 #undef LAUNCH
-    const int total = n_out * n_in_used;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, slabs, nwg, slab_stride, n_in, 0, 0,
-                       n_out, n_in_used, dst, dst_ld, dst_col0);
-    if (dst_bias)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64), dim3(256), 0, st, bias_slabs, nwg,
-                           (size_t)n_out_pad, 1, 0, 0, n_out, 1, dst_bias, 1, 0);
+    const int total = n_out * n_in_used, nb_w = (total + 63) / 64, nb_b = dst_bias ? (n_out + 63) / 64 : 0;
+    const WgradReduceJob jw = {slabs, slab_stride, n_in, n_out, n_in_used, dst_ld, dst_col0, dst};
+    const WgradReduceJob jb = {bias_slabs, (size_t)n_out_pad, 1, n_out, 1, 1, 0, dst_bias};
+    hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3(nb_w + nb_b), dim3(256), 0, st, jw, jb, nb_w, nwg);
     return ddn_launch_status();
 }
 
