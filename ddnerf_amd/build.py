@@ -31,14 +31,14 @@ SOURCES = {
     # beside MFMAs than two v_sub_f32)
     "mlp_x3_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     "mlp_x3_fwd_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
-    "mlp_x3_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+    "mlp_x3_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
 }
 
 
 # kernels whose matrix instructions are inline asm: the compiler's assembly is scanned for dependent pairs that sit closer
 # than the wait states nobody pads (csrc/check_asm_hazards.py); a violation fails the build
 CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel",
-           "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel"}
+           "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel", "mlp_x3_bwd.hip": "mlp_x3_bwd16_kernel"}
 
 
 def _compile_checked(cmd, src, obj, kernel, verbose):

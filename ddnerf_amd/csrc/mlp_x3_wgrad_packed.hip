@@ -43,7 +43,10 @@ __device__ __forceinline__ float xp_value(unsigned w) {
     return __builtin_bit_cast(float, w & 0xffff0000u) + __builtin_bit_cast(float, w << 16);
 }
 
-template <int ROWS> constexpr int xp_nslot() { return ROWS * 64 * 8 <= 160 * 1024 ? 8 : 4; }
+#ifndef XP_NS_BIG
+#define XP_NS_BIG 5
+#endif
+template <int ROWS> constexpr int xp_nslot() { return ROWS * 64 * 8 <= 160 * 1024 ? 8 : (ROWS * 64 * XP_NS_BIG <= 160 * 1024 ? XP_NS_BIG : 4); }
 
 template <int RT, int CT, int RG, int CG, bool BIAS>
 __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned *__restrict__ dT, const unsigned *__restrict__ aT,
@@ -90,9 +93,9 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
         ldst[t] = lds0 + k * 1024;
     }
     // ragged tail: ld is a multiple of 128 >= M, pad columns of `deltas` are zero words, those of `acts` finite
-    auto issue = [&](int u) {
+    auto issue = [&](int u, int ring_pos) {
         const int uc = min(u, nht - 1);  // past the end: harmless repeats into a slot nobody reads again
-        const unsigned slot = (unsigned)(u % NS) * SLOT;
+        const unsigned slot = (unsigned)ring_pos * SLOT;
 #pragma unroll
         for (int t = 0; t < IPW; ++t)
             asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(src[t] + (size_t)uc * XP_STEP), "{m0}"(ldst[t] + slot)
@@ -103,16 +106,19 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
 
     if (nht > 0) {
 #pragma unroll
-        for (int u = 0; u < NS - 1; ++u) issue(u);
+        for (int u = 0; u < NS - 1; ++u) issue(u, u);
     }
+    int rd = 0, wr = NS - 1;  // ring positions of slot u and of slot u + NS - 1
     for (int u = 0; u < nht; ++u) {
         // slot u has landed (this wave's share: all but the transfers of the NS-2 slots issued after it), for every wave; and
         // every wave is done with slot u-1, whose buffer the next transfers overwrite
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue(u + NS - 1);
-        const char *sb = lds_raw + (size_t)(u % NS) * SLOT;
+        issue(u + NS - 1, wr);
+        const char *sb = lds_raw + (size_t)rd * SLOT;
+        rd = rd + 1 == NS ? 0 : rd + 1;
+        wr = wr + 1 == NS ? 0 : wr + 1;
         bf16x8 ah[RT], al[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
