@@ -17,7 +17,7 @@ BF16_FACTOR = cal["calib_bf16rows"] / (524288 * 256 / 1024)   # raw FETCH_SIZE p
 TRUE_KB = 524288 * 512 / 1024
 mfma = {}
 for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512 + 16)), ("bf16", "void mlp_bf16_fwd_kernel<false>", 524288 * (256 + 16)),
-                        ("x3", "void mlp_x3_fwd_kernel<false, 0, 6>", 524288 * (512 + 16))):
+                        ("x3", "void mlp_x3_fwd16_kernel<false>", 524288 * (512 + 16))):
     f = agg(os.path.join(P, "fetch_" + mlp, "c_counter_collection.csv"))
     w = agg(os.path.join(P, "write_" + mlp, "c_counter_collection.csv"))
     table = {}
