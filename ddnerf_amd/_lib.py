@@ -54,7 +54,7 @@ _SIGS = {
     "ddnerf_mlp_x3_wgrad": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
                                        C.c_int, C.c_int, c_fp, c_fp, c_fp]),
     "ddnerf_mlp_x3_wgrad_packed": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
-                                              C.c_int, C.c_int, c_fp, c_fp, c_fp]),
+                                              C.c_int, C.c_int, c_fp, c_fp, C.c_int, c_fp]),
     "ddnerf_mlp_x3_split": (C.c_int, [c_fp, C.c_int, C.c_long, C.c_int, c_fp, c_fp]),
 }
 

@@ -179,7 +179,7 @@ static int n_out_pad_of(int n_out) { return n_out > 128 ? 256 : (n_out > 32 ? 12
 // ddnerf_mlp_x3_split produces them from fp32 matrices.
 DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in,
                                           int n_in_used, long M, long ld, float *dst, int dst_ld, int dst_col0,
-                                          float *dst_bias, float *workspace, ddnerf_stream_t stream) {
+                                          float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
     DDN_REQUIRE(deltas && acts && dst && workspace, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0 && n_out > 0 && n_out <= 256 && n_in_used > 0 && n_in_used <= n_in, DDNERF_E_ARG);
     DDN_REQUIRE(n_in == 32 || n_in == 96 || n_in == 128 || n_in == 256, DDNERF_E_RANGE);
@@ -189,7 +189,10 @@ DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_o
     hipStream_t st = (hipStream_t)stream;
     const int n_out_pad = n_out_pad_of(n_out);
     const long ntiles = (M + XP_TILE - 1) / XP_TILE;
-    const int nwg = (int)(ntiles < 256 ? ntiles : 256);
+    // split-K width: 256 workgroups fill the chip with ONE job; two jobs side by side on two streams (max_workgroups = 128)
+    // write and reduce half the slabs each and overlap each other's prologue / slab epilogue
+    const int cap = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
+    const int nwg = (int)(ntiles < cap ? ntiles : cap);
     const int tiles_per_wg = (int)((ntiles + nwg - 1) / nwg);
     const unsigned *dT = (const unsigned *)deltas + (size_t)drow0 * 16, *aT = (const unsigned *)acts + (size_t)arow0 * 16;
     float *slabs = workspace;

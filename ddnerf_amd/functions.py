@@ -10,17 +10,34 @@ from __future__ import annotations
 
 import torch
 
+from torch.optim.optimizer import register_optimizer_step_post_hook
+
 from . import ops
 
 # ---- MLP -------------------------------------------------------------------------------------------------
+# Fused optimisers (torch.optim.Adam(fused=True): one kernel per step, what TrainStepper uses on the GPU) update the parameters
+# WITHOUT bumping their version counters, so the counters alone would leave a stale weight image behind the first step.  Every
+# optimiser step in the process therefore advances an epoch that is part of the cache tag (an optimiser of another model costs
+# one spare repack, 26 us).
+_OPTIMIZER_EPOCH = [0]
+
+
+def _optimizer_stepped(*_args, **_kwargs):
+    _OPTIMIZER_EPOCH[0] += 1
+
+
+register_optimizer_step_post_hook(_optimizer_stepped)
+
+
 def _cached_pack(net, kind, builder):
     """kernel-format weights, repacked only when a parameter changed (optimizer step, load_state_dict).
     The cache lives ON the module: a global table keyed by id(net) would hand a new model the packed weights of a
     garbage-collected one that happened to get the same id and buffer address.  The parameters alias the flat buffer
-    through `.data`, so in-place updates bump THEIR version counters, not the buffer's: the tag sums those."""
+    through `.data`, so in-place updates bump THEIR version counters, not the buffer's: the tag sums those (and carries the
+    optimiser epoch above)."""
     flat = net.flat_params()
     cache = net.__dict__.setdefault("_packed_cache", {})
-    tag = (flat.data_ptr(), net.param_version())
+    tag = (flat.data_ptr(), net.param_version(), _OPTIMIZER_EPOCH[0])
     hit = cache.get(kind)
     if hit is not None and hit[0] == tag:
         return hit[1]

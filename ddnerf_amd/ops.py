@@ -410,6 +410,17 @@ WGRAD_MODE = os.environ.get("DDNERF_WGRAD", "x3")
 _WGRAD_FN = {"x3": "ddnerf_mlp_x3_wgrad", "f32": "ddnerf_mlp_f32_wgrad", "x3p": "ddnerf_mlp_x3_wgrad_packed"}
 
 
+WGRAD_PAIRED = os.environ.get("DDNERF_WGRAD_PAIRED", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(device, i):
+    key = (str(device), i)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def x3_split(x):
     """fp32 [2560, ld] ([feature][sample]) -> the x3 training tier's record of the same matrix: blocked hi/lo words
     (include/ddnerf_hip.h, ddnerf_mlp_x3_wgrad_packed), in a float32-typed tensor of the same shape (bit patterns, not values)"""
@@ -428,12 +439,13 @@ def x3_unsplit(rec):
 
 
 def mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, dst, dst_ld, dst_col0, dst_bias, workspace,
-                      mode=None):
+                      mode=None, max_wg=0):
     """dst[r*dst_ld + dst_col0 + c] = sum_s deltas[drow0+r][s] * acts[arow0+c][s]; dst_bias[r] = sum_s deltas[drow0+r][s]"""
     mode = mode or WGRAD_MODE
     fn = getattr(_lib.lib(), _WGRAD_FN[mode])
+    extra = (int(max_wg),) if mode == "x3p" else ()
     _lib.check(fn(_ptr(deltas), drow0, n_out, _ptr(acts), arow0, n_in, n_in_used, M, deltas.shape[1], _ptr(dst), dst_ld,
-                  dst_col0, _ptr(dst_bias), _ptr(workspace), _stream()), _WGRAD_FN[mode])
+                  dst_col0, _ptr(dst_bias), _ptr(workspace), *extra, _stream()), _WGRAD_FN[mode])
 
 
 def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
@@ -447,8 +459,28 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
         gv[name] = v
         views.append(v)
         off += p.numel()
-    ws = torch.empty(_lib.lib().ddnerf_mlp_f32_wgrad_workspace_floats(M), dtype=torch.float32, device=acts.device)
-    job = lambda *a: mlp_f32_wgrad_job(deltas, a[0], a[1], acts, a[2], a[3], a[4], M, a[5], a[6], a[7], a[8], ws, mode=mode)
+    nws = _lib.lib().ddnerf_mlp_f32_wgrad_workspace_floats(M)
+    main = torch.cuda.current_stream()
+    pair = mode == "x3p" and WGRAD_PAIRED
+    if pair:
+        # two half-width jobs side by side (each fills half the CUs: one workgroup per CU): half the partial slabs per job, and
+        # one job's prologue / slab epilogue / reduction under the other's main loop
+        lanes = [(_side_stream(acts.device, i), torch.empty(nws, dtype=torch.float32, device=acts.device)) for i in range(2)]
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for st, _ in lanes:
+            st.wait_event(ready)
+    else:
+        lanes = [(main, torch.empty(nws, dtype=torch.float32, device=acts.device))]
+    turn = [0]
+
+    def job(*a):
+        st, ws = lanes[turn[0] % len(lanes)]
+        turn[0] += 1
+        with torch.cuda.stream(st):
+            mlp_f32_wgrad_job(deltas, a[0], a[1], acts, a[2], a[3], a[4], M, a[5], a[6], a[7], a[8], ws, mode=mode,
+                              max_wg=128 if pair else 0)
+
     for l in range(8):
         w, b = gv["layers_xyz.%d.weight" % l], gv["layers_xyz.%d.bias" % l]
         if l == 0:
@@ -460,11 +492,43 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
             job(256 * l, 256, 256 * (l - 1), 256, 256, w, 256, 0, b)
     job(ROW_FEAT, 256, 256 * 7, 256, 256, gv["fc_feat.weight"], 256, 0, gv["fc_feat.bias"])
     wd = gv["layers_dir.0.weight"]
-    job(ROW_DIR, 128, ROW_FEAT, 256, 256, wd, 283, 0, gv["layers_dir.0.bias"])
-    job(ROW_DIR, 128, ROW_X + 96, 32, 27, wd, 283, 256, None)
-    # heads: d(raw) rows 0..2 rgb, 3 alpha, 4..5 mu/sigma (deltas rows ROW_X..)
-    job(ROW_X, 3, ROW_DIR, 128, 128, gv["fc_rgb.weight"], 128, 0, gv["fc_rgb.bias"])
-    job(ROW_X + 3, 1, ROW_FEAT, 256, 256, gv["fc_alpha.weight"], 256, 0, gv["fc_alpha.bias"])
-    if net.depth_head:
-        job(ROW_X + 4, 2, ROW_DIR, 128, 128, gv["fc_mu_sigma.weight"], 128, 0, gv["fc_mu_sigma.bias"])
+    if mode == "x3p":
+        # Jobs that contract over the same activations share ONE pass over them (rows ROW_DIR .. ROW_X + 5 of `deltas` are
+        # adjacent: d(dir hidden) 128 rows, then d(raw): 0..2 rgb, 3 alpha, 4..5 mu / sigma):
+        #   [d(dir hidden) ; d(raw)] x fc_feat out  -> the dir layer's hidden columns and fc_alpha   (saves 288 - 32 rows x M)
+        #   d(raw) x dir hidden                     -> fc_rgb and fc_mu_sigma                        (saves 160 rows x M)
+        # the sub-blocks are copied out of two small scratch matrices (rows of no interest are products nobody reads).
+        t1 = torch.empty((160, 256), dtype=torch.float32, device=acts.device)
+        b1 = torch.empty(160, dtype=torch.float32, device=acts.device)
+        t2 = torch.empty((6, 128), dtype=torch.float32, device=acts.device)
+        b2 = torch.empty(6, dtype=torch.float32, device=acts.device)
+        job(ROW_DIR, 160, ROW_FEAT, 256, 256, t1, 256, 0, b1)
+        st1 = lanes[(turn[0] - 1) % len(lanes)][0]
+        job(ROW_X, 6, ROW_DIR, 128, 128, t2, 128, 0, b2)
+        st2 = lanes[(turn[0] - 1) % len(lanes)][0]
+        job(ROW_DIR, 128, ROW_X + 96, 32, 27, wd, 283, 256, None)
+        with torch.cuda.stream(st1):
+            wd[:, :256].copy_(t1[:128])
+            gv["layers_dir.0.bias"].copy_(b1[:128])
+            gv["fc_alpha.weight"].copy_(t1[131:132])
+            gv["fc_alpha.bias"].copy_(b1[131:132])
+        with torch.cuda.stream(st2):
+            gv["fc_rgb.weight"].copy_(t2[:3])
+            gv["fc_rgb.bias"].copy_(b2[:3])
+            if net.depth_head:
+                gv["fc_mu_sigma.weight"].copy_(t2[4:6])
+                gv["fc_mu_sigma.bias"].copy_(b2[4:6])
+    else:
+        job(ROW_DIR, 128, ROW_FEAT, 256, 256, wd, 283, 0, gv["layers_dir.0.bias"])
+        job(ROW_DIR, 128, ROW_X + 96, 32, 27, wd, 283, 256, None)
+        # heads: d(raw) rows 0..2 rgb, 3 alpha, 4..5 mu/sigma (deltas rows ROW_X..)
+        job(ROW_X, 3, ROW_DIR, 128, 128, gv["fc_rgb.weight"], 128, 0, gv["fc_rgb.bias"])
+        job(ROW_X + 3, 1, ROW_FEAT, 256, 256, gv["fc_alpha.weight"], 256, 0, gv["fc_alpha.bias"])
+        if net.depth_head:
+            job(ROW_X + 4, 2, ROW_DIR, 128, 128, gv["fc_mu_sigma.weight"], 128, 0, gv["fc_mu_sigma.bias"])
+    if pair:
+        for st, _ in lanes:  # the caller's stream continues behind both lanes (which also orders the frees of acts / deltas / ws)
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
     return flat_g, views

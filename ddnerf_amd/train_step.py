@@ -3,6 +3,8 @@ parallel.  Loss assembly, the two Adam optimisers and the schedules are the refe
 nothing forces a host sync per iteration (the reference calls .item() twice per step for logging)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import dist as ddp
@@ -15,9 +17,13 @@ class TrainStepper:
         self.dd = cfg.nerf.type == "DDNerfModel"
         if optimizers is None:  # train_model.py:84-98: one optimiser per network, lr set per step
             opt = getattr(torch.optim, cfg.optimizer.type)
-            optimizers = [opt(model.coarse.parameters(), lr=cfg.optimizer.lr)]
+            # (same update rule; on the GPU torch's fused implementation is ONE kernel per optimiser instead of six multi-tensor
+            # launches: 0.29 -> 0.08 ms of a 10 ms step)
+            on_gpu = next(model.coarse.parameters()).is_cuda
+            kw = {"fused": True} if (on_gpu and cfg.optimizer.type in ("Adam", "AdamW") and os.environ.get("DDNERF_FUSED_ADAM", "1") != "0") else {}
+            optimizers = [opt(model.coarse.parameters(), lr=cfg.optimizer.lr, **kw)]
             if cfg.nerf.type != "GeneralMipNerfModel":
-                optimizers.append(opt(model.fine.parameters(), lr=cfg.optimizer.lr))
+                optimizers.append(opt(model.fine.parameters(), lr=cfg.optimizer.lr, **kw))
         self.optims = optimizers
         self.smooth = schedules.SmoothingSchedule(cfg)
         self.buckets = ddp.GradBuckets([model.fine, model.coarse], single_rank_collectives=single_rank_collectives) if dist else None

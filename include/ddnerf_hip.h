@@ -232,11 +232,13 @@ int ddnerf_mlp_x3_wgrad(const float *deltas, int drow0, int n_out, const float *
  * compute for their own next layer anyway), at word index ((m >> 4) * 2560 + row) * 16 + (m & 15): 16-sample blocks, the
  * rows of a block back to back.  A job's rows of a block are one contiguous run that travels HBM -> LDS by LDS-DMA and feeds
  * the MFMAs without a split pass (4.7 TB/s where the [row][sample] fp32 operands of ddnerf_mlp_x3_wgrad reach 3.3).  ld must
- * be a multiple of 32.  Weight gradients are bit-identical to ddnerf_mlp_x3_wgrad on the fp32 matrices the words were split
- * from; bias sums add hi + lo (2^-17 relative per term). */
+ * be a multiple of 32.  max_workgroups (0 = 256) caps the split-K width: with 128, two jobs enqueued on two streams (each
+ * with its own workspace) share the chip and write half the partial slabs each.  At the default width the weight gradients
+ * are bit-identical to ddnerf_mlp_x3_wgrad on the fp32 matrices the words were split from (another width is another -- equally
+ * fixed -- summation order); bias sums add hi + lo (2^-17 relative per term). */
 int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
                                 long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
-                                ddnerf_stream_t stream);
+                                int max_workgroups, ddnerf_stream_t stream);
 /* fp32 [rows][ld] ([feature][sample], ld a multiple of 16) -> rows row0 .. row0 + rows - 1 of such a record. */
 int ddnerf_mlp_x3_split(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream);
 
