@@ -55,6 +55,7 @@ _SIGS = {
                                        C.c_int, C.c_int, c_fp, c_fp, c_fp]),
     "ddnerf_mlp_x3_wgrad_packed": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
                                               C.c_int, C.c_int, c_fp, c_fp, C.c_int, c_fp]),
+    "ddnerf_mlp_x3_wgrad_packed_skip": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_long, C.c_long, c_fp, c_fp, c_fp, C.c_int, c_fp]),
     "ddnerf_mlp_x3_split": (C.c_int, [c_fp, C.c_int, C.c_long, C.c_int, c_fp, c_fp]),
 }
 

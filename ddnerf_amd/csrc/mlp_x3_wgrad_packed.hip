@@ -48,9 +48,11 @@ __device__ __forceinline__ float xp_value(unsigned w) {
 #endif
 template <int ROWS> constexpr int xp_nslot() { return ROWS * 64 * 8 <= 160 * 1024 ? 8 : (ROWS * 64 * XP_NS_BIG <= 160 * 1024 ? XP_NS_BIG : 4); }
 
-template <int RT, int CT, int RG, int CG, bool BIAS>
+// NINA > 0: the activation rows come from TWO row ranges of the record, the first NINA from aT, the others from aT2 (layers_xyz.5
+// contracts its deltas over cat(xyz, h4): rows 2432.. and rows 1024..; one pass over the deltas instead of two jobs)
+template <int RT, int CT, int RG, int CG, bool BIAS, int NINA = 0>
 __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned *__restrict__ dT, const unsigned *__restrict__ aT,
-                                                                  long M, long ld, int tiles_per_wg,
+                                                                  const unsigned *__restrict__ aT2, long M, long ld, int tiles_per_wg,
                                                                   float *__restrict__ slabs, float *__restrict__ bias_slabs) {
     constexpr int NOP = 32 * RT * RG, NIN = 32 * CT * CG, NW = RG * CG, THREADS = 64 * NW, ROWS = NOP + NIN;
     constexpr int NI = ROWS / 16, IPW = (NI + NW - 1) / NW;  // transfer instructions per slot / per wave (surplus ones repeat the last)
@@ -88,8 +90,9 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
         const int row = 16 * k + (lane >> 2);
         const int q = (lane & 3) ^ ((lane >> 4) & 3);                  // source chunk of LDS chunk (lane & 3): (row >> 2) & 3 swizzle
         const bool in_d = 16 * k < NOP;                                // (uniform; NOP is a multiple of 16)
-        voff[t] = (unsigned)((in_d ? row : row - NOP) * 64 + q * 16);
-        src[t] = (const char *)(in_d ? dT : aT) + (size_t)tile0 * 2 * XP_STEP;
+        const bool in_a2 = NINA > 0 && 16 * k >= NOP + NINA;           // (uniform; NINA is a multiple of 16)
+        voff[t] = (unsigned)((in_d ? row : (in_a2 ? row - NOP - NINA : row - NOP)) * 64 + q * 16);
+        src[t] = (const char *)(in_d ? dT : (in_a2 ? aT2 : aT)) + (size_t)tile0 * 2 * XP_STEP;
         ldst[t] = lds0 + k * 1024;
     }
     // ragged tail: ld is a multiple of 128 >= M, pad columns of `deltas` are zero words, those of `acts` finite
@@ -203,10 +206,10 @@ DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_o
         constexpr int ROWS_ = 32 * RT * RG + 32 * CT * CG;                                                              \
         const size_t lds = (size_t)ROWS_ * 64 * xp_nslot<ROWS_>();                                                      \
         if (bias_slabs)                                                                                                 \
-            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, true>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, M, ld, \
+            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, true>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
                                tiles_per_wg, slabs, bias_slabs);                                                        \
         else                                                                                                            \
-            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, false>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, M, ld, \
+            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, false>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
                                tiles_per_wg, slabs, bias_slabs);                                                        \
     } while (0)
     if (n_out_pad == 256) {
@@ -220,6 +223,34 @@ DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_o
     const int total = n_out * n_in_used, nb_w = (total + 63) / 64, nb_b = dst_bias ? (n_out + 63) / 64 : 0;
     const WgradReduceJob jw = {slabs, slab_stride, n_in, n_out, n_in_used, dst_ld, dst_col0, dst};
     const WgradReduceJob jb = {bias_slabs, (size_t)n_out_pad, 1, n_out, 1, 1, 0, dst_bias};
+    hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3(nb_w + nb_b), dim3(256), 0, st, jw, jb, nb_w, nwg);
+    return ddn_launch_status();
+}
+
+// layers_xyz.5 in ONE job: dst[r * 352 + c] for the 256 rows drow0.. of `deltas` against cat(acts rows arow_a .. +96, acts rows
+// arow_b .. +256) -- the column order of the reference's cat(xyz, h) input -- and the bias sums.
+DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
+                                               float *dst, float *dst_bias, float *workspace, int max_workgroups,
+                                               ddnerf_stream_t stream) {
+    DDN_REQUIRE(deltas && acts && dst && dst_bias && workspace, DDNERF_E_ARG);
+    DDN_REQUIRE(M > 0 && ld % 32 == 0 && ld >= M, DDNERF_E_RANGE);
+    DDN_REQUIRE(drow0 >= 0 && arow_a >= 0 && arow_b >= 0 && drow0 + 256 <= XP_ROWS && arow_a + 96 <= XP_ROWS && arow_b + 256 <= XP_ROWS,
+                DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(deltas, 16) && ddn_aligned(acts, 16), DDNERF_E_ALIGN);
+    hipStream_t st = (hipStream_t)stream;
+    const long ntiles = (M + XP_TILE - 1) / XP_TILE;
+    const int cap = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
+    const int nwg = (int)(ntiles < cap ? ntiles : cap);
+    const int tiles_per_wg = (int)((ntiles + nwg - 1) / nwg);
+    const unsigned *dT = (const unsigned *)deltas + (size_t)drow0 * 16;
+    const unsigned *aA = (const unsigned *)acts + (size_t)arow_a * 16, *aB = (const unsigned *)acts + (size_t)arow_b * 16;
+    constexpr int NIN = 352, ROWS = 256 + NIN;
+    float *slabs = workspace, *bias_slabs = workspace + (size_t)nwg * 256 * NIN;
+    hipLaunchKernelGGL((wgrad_x3p_kernel<1, 11, 8, 1, true, 96>), dim3(nwg), dim3(512), (size_t)ROWS * 64 * xp_nslot<ROWS>(), st, dT, aA, aB, M, ld,
+                       tiles_per_wg, slabs, bias_slabs);
+    const int total = 256 * NIN, nb_w = (total + 63) / 64, nb_b = (256 + 63) / 64;
+    const WgradReduceJob jw = {slabs, (size_t)256 * NIN, NIN, 256, NIN, NIN, 0, dst};
+    const WgradReduceJob jb = {bias_slabs, (size_t)256, 1, 256, 1, 1, 0, dst_bias};
     hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3(nb_w + nb_b), dim3(256), 0, st, jw, jb, nb_w, nwg);
     return ddn_launch_status();
 }

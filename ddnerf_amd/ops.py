@@ -485,6 +485,13 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
         w, b = gv["layers_xyz.%d.weight" % l], gv["layers_xyz.%d.bias" % l]
         if l == 0:
             job(0, 256, ROW_X, 96, 96, w, 96, 0, b)
+        elif l == 5 and mode == "x3p":  # cat(xyz, h4) in one pass over the deltas
+            st, ws = lanes[turn[0] % len(lanes)]
+            turn[0] += 1
+            with torch.cuda.stream(st):
+                _lib.check(_lib.lib().ddnerf_mlp_x3_wgrad_packed_skip(_ptr(deltas), 1280, _ptr(acts), ROW_X, 1024, M, deltas.shape[1], _ptr(w),
+                                                                      _ptr(b), _ptr(ws), 128 if pair else 0, _stream()),
+                           "ddnerf_mlp_x3_wgrad_packed_skip")
         elif l == 5:
             job(1280, 256, ROW_X, 96, 96, w, 352, 0, b)
             job(1280, 256, 1024, 256, 256, w, 352, 96, None)

@@ -239,6 +239,10 @@ int ddnerf_mlp_x3_wgrad(const float *deltas, int drow0, int n_out, const float *
 int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
                                 long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
                                 int max_workgroups, ddnerf_stream_t stream);
+/* layers_xyz.5 (input cat(xyz, h4)) as ONE job over the same records: dst [256][352] = rows drow0.. of `deltas` against
+ * cat(acts rows arow_a .. +96, acts rows arow_b .. +256); dst_bias [256]. */
+int ddnerf_mlp_x3_wgrad_packed_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
+                                     float *dst, float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream);
 /* fp32 [rows][ld] ([feature][sample], ld a multiple of 16) -> rows row0 .. row0 + rows - 1 of such a record. */
 int ddnerf_mlp_x3_split(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream);
 

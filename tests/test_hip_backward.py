@@ -324,6 +324,18 @@ def test_weight_gradient_kernels_at_full_size(ops):
                 assert float(w[:, :col0].abs().max()) == 0.0          # columns outside the job are not touched
         assert float((outs["x3"][0] - outs["f32"][0]).abs().max()) <= 5e-5 * scale
         assert torch.equal(outs["x3"][0], outs["x3p"][0])   # same splits, same partition, same MFMA order: bit-identical
+    # layers_xyz.5 as one job over cat(xyz rows, h4 rows) == its two single-range jobs
+    w2 = torch.zeros(256, 352, device="cuda")
+    b2 = torch.zeros(256, device="cuda")
+    ops.mlp_f32_wgrad_job(rec_d, 1280, 256, rec_a, 2432, 96, 96, M, w2, 352, 0, b2, ws, mode="x3p")
+    ops.mlp_f32_wgrad_job(rec_d, 1280, 256, rec_a, 1024, 256, 256, M, w2, 352, 96, None, ws, mode="x3p")
+    w1 = torch.zeros(256, 352, device="cuda")
+    b1 = torch.zeros(256, device="cuda")
+    ops._lib.check(ops._lib.lib().ddnerf_mlp_x3_wgrad_packed_skip(rec_d.data_ptr(), 1280, rec_a.data_ptr(), 2432, 1024, M, rec_d.shape[1],
+                                                                  w1.data_ptr(), b1.data_ptr(), ws.data_ptr(), 0,
+                                                                  torch.cuda.current_stream().cuda_stream), "skip")
+    assert torch.equal(w1, w2)
+    assert float((b1 - b2).abs().max()) <= 1e-6 * float(b2.abs().max())
 
 
 def test_training_kernels_at_full_size(ops):
