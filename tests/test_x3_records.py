@@ -8,6 +8,13 @@ import torch
 ROWS = 2560
 
 
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from ddnerf_amd import ops as _ops
+    return _ops
+
+
 def words_of(x):
     """fp32 array -> uint32 words (bf16(x) << 16) | bf16(x - bf16(x)), round-to-nearest-even conversions"""
     t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
