@@ -46,6 +46,8 @@ _SIGS = {
     "ddnerf_mlp_f32_pack_t": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_f32_forward_train": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_mlp_f32_backward_data": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_mlp_f32_forward_train_rec": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_mlp_f32_backward_data_rec": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_ray_bundle": (C.c_int, [C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_mlp_f32_wgrad_workspace_floats": (C.c_size_t, [C.c_long]),

@@ -22,6 +22,7 @@ SOURCES = {
     "raygen.hip": EXACT,
     "mlp_f32.hip": [],
     "mlp_f32_train.hip": [],
+    "mlp_f32_train_rec.hip": [],
     "mlp_f32_wgrad.hip": [],
     "mlp_x3_wgrad.hip": [],
     "mlp_x3_wgrad_packed.hip": [],

@@ -67,8 +67,10 @@ static PlanT make_plan_t(int depth_head) {
     return p;
 }
 
+#ifndef F32_REC
 DDN_EXPORT size_t ddnerf_mlp_f32_packed_t_floats(int depth_head) { return (size_t)make_plan_t(depth_head).total; }
 DDN_EXPORT size_t ddnerf_mlp_act_rows(void) { return ACT_ROWS; }
+#endif
 
 // A^T element of backward step d: row c (feature of the outgoing delta), column o (row of the incoming delta)
 __device__ __forceinline__ float src_wt(const float *__restrict__ P, const PlanT &pl, int d, int c, int o) {
@@ -88,6 +90,7 @@ __device__ __forceinline__ float src_wt(const float *__restrict__ P, const PlanT
     return P[pl.w_src[l] + o * 256 + c];
 }
 
+#ifndef F32_REC
 __global__ void mlp_f32_pack_t_kernel(const float *__restrict__ P, PlanT pl, float *__restrict__ packed) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= pl.total) return;
@@ -111,12 +114,41 @@ DDN_EXPORT int ddnerf_mlp_f32_pack_t(const float *params, int depth_head, float 
                        packed_t);
     return ddn_launch_status();
 }
+#endif
 
 #define TADDR(row, ld, col) ((size_t)(row) * (ld) + (col))
 // streaming data is written / read non-temporally: it must not evict the weight slices every block re-reads from L2
 #define TSTORE(v, p) __builtin_nontemporal_store(v, p)
 #define TLOAD(p) __builtin_nontemporal_load(p)
 // ---- shared: store / load one accumulator tile in the transposed [feature][sample] matrices -------------------
+#ifdef F32_REC
+// Second build of this file (mlp_f32_train_rec.hip): `acts` / `deltas` are RECORDS of blocked hi/lo words, the operand format of
+// the packed weight-gradient kernel (include/ddnerf_hip.h, ddnerf_mlp_x3_wgrad_packed): element (row, sample m) = one word
+// (bf16 hi << 16) | bf16 lo at word index ((m >> 4) * 2560 + row) * 16 + (m & 15).  The bf16x3 weight gradients split the
+// fp32 values exactly like this anyway; recording the split lets them stream contiguous runs at 4.5 - 5 TB/s instead of
+// [feature][sample] rows at 3.  A value is > 0 iff its word is != 0.
+#define F32_NAME(x) x##_rec
+__device__ __forceinline__ unsigned rec_word(float x) {
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    return ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | __builtin_bit_cast(unsigned short, lo);
+}
+__device__ __forceinline__ size_t rec_base(int row0, size_t col, int h) { return ((col >> 4) * ACT_ROWS + row0 + 4 * h) * 16 + (col & 15); }
+__device__ __forceinline__ void store_tile_t(float *__restrict__ mat, size_t, int row0, size_t col, int h, const f32x16 &v) {
+    unsigned *p = (unsigned *)mat + rec_base(row0, col, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) TSTORE(rec_word(v[r]), p + tile_row(r, 0) * 16);
+}
+__device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, size_t, int row0, size_t col, int h) {
+    const float *p = mat + rec_base(row0, col, h);
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = TLOAD(p + tile_row(r, 0) * 16);
+    return v;
+}
+__device__ __forceinline__ bool tile_positive(float w) { return __builtin_bit_cast(unsigned, w) != 0u; }
+#else
+#define F32_NAME(x) x
 __device__ __forceinline__ void store_tile_t(float *__restrict__ mat, size_t ld, int row0, size_t col, int h,
                                              const f32x16 &v) {
 #pragma unroll
@@ -128,6 +160,8 @@ __device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, siz
     for (int r = 0; r < 16; ++r) v[r] = TLOAD(&mat[TADDR(row0 + tile_row(r, h), ld, col)]);
     return v;
 }
+__device__ __forceinline__ bool tile_positive(float a) { return a > 0.0f; }
+#endif
 
 template <int DST, int B0, int NBLK>
 __device__ __forceinline__ void load_features(const float *__restrict__ frow, int h, f32x16 (&Breg)[12]) {
@@ -187,7 +221,7 @@ struct FwdOffsets {
 };
 
 template <bool DEPTH>
-__global__ __launch_bounds__(256, 1) void mlp_f32_fwd_train_kernel(const float *__restrict__ feat,
+__global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_fwd_train_kernel)(const float *__restrict__ feat,
                                                                    const float *__restrict__ packed, FwdOffsets fo,
                                                                    float *__restrict__ raw, float *__restrict__ acts,
                                                                    long M, long ld) {
@@ -272,7 +306,7 @@ static FwdOffsets fwd_offsets() {
     return fo;
 }
 
-DDN_EXPORT int ddnerf_mlp_f32_forward_train(const float *feat, const float *packed, int depth_head, float *raw,
+DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_forward_train)(const float *feat, const float *packed, int depth_head, float *raw,
                                             float *acts, long M, long ld, ddnerf_stream_t stream) {
     DDN_REQUIRE(feat && packed && raw && acts, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
@@ -281,10 +315,10 @@ DDN_EXPORT int ddnerf_mlp_f32_forward_train(const float *feat, const float *pack
     FwdOffsets fo = fwd_offsets();
     dim3 grid((unsigned)((M + 127) / 128));
     if (depth_head)
-        hipLaunchKernelGGL(mlp_f32_fwd_train_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
+        hipLaunchKernelGGL(F32_NAME(mlp_f32_fwd_train_kernel)<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
                            acts, M, ld);
     else
-        hipLaunchKernelGGL(mlp_f32_fwd_train_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
+        hipLaunchKernelGGL(F32_NAME(mlp_f32_fwd_train_kernel)<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
                            acts, M, ld);
     return ddn_launch_status();
 }
@@ -314,7 +348,7 @@ __device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *l
         auto post = [&](f32x16 &a) {
             if (MASK) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] = act[r] > 0.0f ? a[r] : 0.0f;
+                for (int r = 0; r < 16; ++r) a[r] = tile_positive(act[r]) ? a[r] : 0.0f;
             }
             store_tile_t(deltas, ld, row0 + 32 * b, col, h, a);
         };
@@ -324,7 +358,7 @@ __device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *l
 }
 
 template <bool DEPTH>
-__global__ __launch_bounds__(256, 1) void mlp_f32_bwd_data_kernel(const float *__restrict__ g_raw,
+__global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_bwd_data_kernel)(const float *__restrict__ g_raw,
                                                                   const float *__restrict__ packed_t,
                                                                   const float *__restrict__ acts,
                                                                   float *__restrict__ deltas, long M, long ld) {
@@ -378,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_bwd_data_kernel(const float *_
     step_bwd<1, 256, 8, 0, 0, true>(wp, lds, Breg, out, acts, deltas, ld, 0, m, tid, lane);
 }
 
-DDN_EXPORT int ddnerf_mlp_f32_backward_data(const float *g_raw, const float *packed_t, const float *acts,
+DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_backward_data)(const float *g_raw, const float *packed_t, const float *acts,
                                             int depth_head, float *deltas, long M, long ld, ddnerf_stream_t stream) {
     DDN_REQUIRE(g_raw && packed_t && acts && deltas, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
@@ -386,10 +420,10 @@ DDN_EXPORT int ddnerf_mlp_f32_backward_data(const float *g_raw, const float *pac
     DDN_REQUIRE(ddn_aligned(packed_t, 16), DDNERF_E_ALIGN);
     dim3 grid((unsigned)((M + 127) / 128));
     if (depth_head)
-        hipLaunchKernelGGL(mlp_f32_bwd_data_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, acts,
+        hipLaunchKernelGGL(F32_NAME(mlp_f32_bwd_data_kernel)<true>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, acts,
                            deltas, M, ld);
     else
-        hipLaunchKernelGGL(mlp_f32_bwd_data_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, acts,
+        hipLaunchKernelGGL(F32_NAME(mlp_f32_bwd_data_kernel)<false>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, acts,
                            deltas, M, ld);
     return ddn_launch_status();
 }

@@ -68,12 +68,15 @@ class _MLPFunction(torch.autograd.Function):
         if net.mlp_dtype == "bf16":
             raise NotImplementedError("training runs on the fp32 / x3 MLP kernels; the plain bf16 kernel is inference-only")
         ctx.x3 = net.mlp_dtype == "x3"
+        ctx.rec = False
         packed = _packed_weights(net)
         if ctx.x3:
             raw, acts, bits = ops.mlp_x3_forward_train(feat, packed, net.depth_head)
             ctx.save_for_backward(feat, acts, bits)
         else:
-            raw, acts = ops.mlp_f32_forward_train(feat, packed, net.depth_head)
+            # with the default (bf16x3) weight gradients the exact-fp32 kernels record hi/lo words for the packed-operand kernel
+            ctx.rec = ops.WGRAD_MODE == "x3"
+            raw, acts = ops.mlp_f32_forward_train(feat, packed, net.depth_head, rec=ctx.rec)
             ctx.save_for_backward(feat, acts)
         net._fwd_calls = getattr(net, "_fwd_calls", 0) + 1
         ctx.net = net
@@ -90,9 +93,9 @@ class _MLPFunction(torch.autograd.Function):
         else:
             feat, acts = ctx.saved_tensors
             packed_t = _cached_pack(net, "fp32_t", ops.mlp_f32_pack_t)
-            deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head)
-        # (the x3 kernels record hi/lo words for the packed-operand weight-gradient kernel; DDNERF_WGRAD=f32 cannot read them)
-        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3p" if ctx.x3 else None)
+            deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head, rec=ctx.rec)
+        # (records of hi/lo words go to the packed-operand weight-gradient kernel; DDNERF_WGRAD=f32 keeps fp32 matrices)
+        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3p" if (ctx.x3 or ctx.rec) else None)
         net.last_flat_grad = flat_g  # the data-parallel bucket (ddnerf_amd.dist) reduces this buffer
         reducer = getattr(net, "grad_reducer", None)
         if reducer is not None:

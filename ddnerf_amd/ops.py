@@ -311,8 +311,10 @@ def mlp_f32_pack_t(params_flat, depth_head):
     return packed
 
 
-def mlp_f32_forward_train(feat, packed, depth_head):
-    """forward + recorded activations: returns raw [M,4|6], acts [2432, ld] (transposed: row = feature)"""
+def mlp_f32_forward_train(feat, packed, depth_head, rec=False):
+    """forward + recorded activations: returns raw [M,4|6], acts [2560, ld] (fp32, transposed: row = feature; rec=True: a
+    record of blocked hi/lo words instead -- x3_unsplit reads it back -- for the packed-operand weight-gradient kernel)"""
+    fn = "ddnerf_mlp_f32_forward_train" + ("_rec" if rec else "")
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
     ld = (M + 127) // 128 * 128
@@ -320,8 +322,7 @@ def mlp_f32_forward_train(feat, packed, depth_head):
     acts = torch.empty((ACT_ROWS, ld), dtype=torch.float32, device=feat.device)
 
     def launch():
-        _lib.check(_lib.lib().ddnerf_mlp_f32_forward_train(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts),
-                                                           M, ld, _stream()), "ddnerf_mlp_f32_forward_train")
+        _lib.check(getattr(_lib.lib(), fn)(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts), M, ld, _stream()), fn)
 
     if MLP_LAUNCH_HOOK is not None:
         MLP_LAUNCH_HOOK(M, launch)
@@ -330,13 +331,14 @@ def mlp_f32_forward_train(feat, packed, depth_head):
     return raw, acts
 
 
-def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head):
+def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head, rec=False):
+    """rec: `acts` is a record (mlp_f32_forward_train(rec=True)) and so is the result"""
+    fn = "ddnerf_mlp_f32_backward_data" + ("_rec" if rec else "")
     g_raw = _f32c(g_raw, "g_raw")
     M = g_raw.shape[0]
     ld = acts.shape[1]
     deltas = torch.empty_like(acts)
-    _lib.check(_lib.lib().ddnerf_mlp_f32_backward_data(_ptr(g_raw), _ptr(packed_t), _ptr(acts), int(depth_head),
-                                                       _ptr(deltas), M, ld, _stream()), "ddnerf_mlp_f32_backward_data")
+    _lib.check(getattr(_lib.lib(), fn)(_ptr(g_raw), _ptr(packed_t), _ptr(acts), int(depth_head), _ptr(deltas), M, ld, _stream()), fn)
     return deltas
 
 

@@ -217,6 +217,13 @@ int ddnerf_mlp_f32_forward_train(const float *feat, const float *packed, int dep
                                  long ld, ddnerf_stream_t stream);
 int ddnerf_mlp_f32_backward_data(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
                                  float *deltas, long M, long ld, ddnerf_stream_t stream);
+/* The same two kernels with `acts` / `deltas` as records of blocked hi/lo words (see ddnerf_mlp_x3_wgrad_packed below): the
+ * exact-fp32 forward / backward arithmetic, recording each value's exact hi/lo split -- the operands of the packed weight-gradient
+ * kernel.  (The fp32 [feature][sample] variants above feed ddnerf_mlp_f32_wgrad / ddnerf_mlp_x3_wgrad.) */
+int ddnerf_mlp_f32_forward_train_rec(const float *feat, const float *packed, int depth_head, float *raw, float *acts, long M,
+                                 long ld, ddnerf_stream_t stream);
+int ddnerf_mlp_f32_backward_data_rec(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
+                                 float *deltas, long M, long ld, ddnerf_stream_t stream);
 size_t ddnerf_mlp_f32_wgrad_workspace_floats(long M);
 int ddnerf_mlp_f32_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,
                          long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,

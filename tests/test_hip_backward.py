@@ -361,6 +361,14 @@ def test_training_kernels_at_full_size(ops):
     assert torch.equal(ops.x3_split(acts_f).view(torch.int32).view(-1, 2560, 16)[:, 2432:2555], acts_x.view(torch.int32).view(-1, 2560, 16)[:, 2432:2555])
     d_f = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_f, depth)
     d_x = ops.mlp_x3_backward_data(G, ops.mlp_x3_pack_t(flat, depth), bits, depth)
+    # the exact-fp32 kernels' record-writing build (what the fp32 tier runs with the default weight gradients): the same
+    # values, stored as their exact hi/lo split in the blocked layout -- bit for bit the split of the fp32 matrices
+    raw_r, acts_r = ops.mlp_f32_forward_train(feat, ops.mlp_f32_pack(flat, depth), depth, rec=True)
+    assert torch.equal(raw_r, raw_f)
+    assert torch.equal(acts_r.view(torch.int32)[:, :M].reshape(-1, 2560, 16)[:, :2555], ops.x3_split(acts_f).view(torch.int32)[:, :M].reshape(-1, 2560, 16)[:, :2555])
+    d_r = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_r, depth, rec=True)
+    assert torch.equal(d_r.view(torch.int32).reshape(-1, 2560, 16)[:, :2438], ops.x3_split(d_f).view(torch.int32).reshape(-1, 2560, 16)[:, :2438])
+    del raw_r, acts_r, d_r
     rows = torch.cat([torch.arange(0, 2432, 41, device="cuda"), torch.arange(2432, 2438, device="cuda")])
     a, b = d_f[rows], ops.x3_unsplit(d_x)[rows]
     off = (a - b).abs() > 1e-4 * float(a.abs().max())
