@@ -118,7 +118,12 @@ DDN_EXPORT int ddnerf_mlp_f32_pack_t(const float *params, int depth_head, float 
 
 #define TADDR(row, ld, col) ((size_t)(row) * (ld) + (col))
 // streaming data is written / read non-temporally: it must not evict the weight slices every block re-reads from L2
+#ifdef F32_REC  // the record build writes two 64-byte half lines per store: write-back caching merges them (19.9 -> 19.4 ms per
+                // fp32 training step; in the MFMA-bound x3 kernels the same change costs time, mlp_mfma16.inc)
+#define TSTORE(v, p) (*(p) = (v))
+#else
 #define TSTORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 #define TLOAD(p) __builtin_nontemporal_load(p)
 // ---- shared: store / load one accumulator tile in the transposed [feature][sample] matrices -------------------
 #ifdef F32_REC
