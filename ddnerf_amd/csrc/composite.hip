@@ -380,38 +380,28 @@ __global__ __launch_bounds__(256) void dd_records_count_kernel(const float *__re
     if (lane == 0) counts[ray] = cnt;
 }
 
-__global__ __launch_bounds__(1024) void dd_records_scan_kernel(const int *__restrict__ counts, int n, int *__restrict__ offsets,
-                                                              int *__restrict__ total) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = tid * per, hi = min(n, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += counts[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int base = tid > 0 ? part[tid - 1] : 0;
-    for (int i = lo; i < hi; ++i) {
-        offsets[i] = base;
-        base += counts[i];
-    }
-    if (tid == 1023) *total = part[1023];
-}
 
+// Every block finds the output offset of its own rays by counting what the rays in front of it keep (integer sums over the
+// count kernel's per-ray counts: no scan launch in between); the block that owns the last ray also writes the total.
 __global__ __launch_bounds__(256) void dd_records_write_kernel(const unsigned char *__restrict__ flags,
-                                                              const int *__restrict__ offsets, const float *__restrict__ mus,
+                                                              const int *__restrict__ counts, const float *__restrict__ mus,
                                                               const float *__restrict__ sigmas, const float *__restrict__ ssig,
                                                               int n, int nc, float *__restrict__ out_mus,
-                                                              float *__restrict__ out_sigmas, float *__restrict__ out_ssig) {
-    const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                              float *__restrict__ out_sigmas, float *__restrict__ out_ssig,
+                                                              int *__restrict__ total) {
+    __shared__ int part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ray = blockIdx.x * 4 + wave;
+    const int first = blockIdx.x * 4;
+    int before = 0;
+    for (int i = threadIdx.x; i < first; i += 256) before += counts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if (lane == 0) part[wave] = before;
+    __syncthreads();
+    int base = part[0] + part[1] + part[2] + part[3];
+    for (int i = first; i < ray && i < n; ++i) base += counts[i];
+    if (ray == n - 1 && lane == 0) *total = base + counts[ray];
     if (ray >= n) return;
-    int base = offsets[ray];
     for (int j0 = 0; j0 < nc; j0 += 64) {
         const int j = j0 + lane;
         const bool f = j < nc && flags[(size_t)ray * nc + j];
@@ -441,8 +431,7 @@ DDN_EXPORT int ddnerf_dd_records(const float *weights, const float *mus, const f
     unsigned char *flags = (unsigned char *)(offsets + n + 1);
     dim3 grid((unsigned)((n + 3) / 4));
     hipLaunchKernelGGL(dd_records_count_kernel, grid, dim3(256), 0, st, weights, n, nc, flags, counts);
-    hipLaunchKernelGGL(dd_records_scan_kernel, dim3(1), dim3(1024), 0, st, counts, n, offsets, total);
-    hipLaunchKernelGGL(dd_records_write_kernel, grid, dim3(256), 0, st, flags, offsets, mus, sigmas, ssig, n, nc, out_mus,
-                       out_sigmas, out_ssig);
+    hipLaunchKernelGGL(dd_records_write_kernel, grid, dim3(256), 0, st, flags, counts, mus, sigmas, ssig, n, nc, out_mus,
+                       out_sigmas, out_ssig, total);
     return ddn_launch_status();
 }

@@ -3,13 +3,44 @@
 //
 // Stages (all on the caller's stream, no host sync):
 //   1. keep[i]   = blender ? torch.sum(w1[i]) > 1e-10 : 1                      (:16)   wave per row
-//   2. rank[i]   = exclusive prefix count of keep (fixed order), R = total     (:22-28) one block
+//   2. rank[i]   = exclusive prefix count of keep, R = number of kept rows      (:22-28) every block of step 3 counts the
+//                  flags in front of its own rows itself (integer sums), the finish kernel counts them all: no scan launch
 //   3. rowsum[r] = sum_m kl(m) of kept row i (r = rank[i]); bug-for-bug: left_tails_0 is read at
 //                  row r, not row i, because the reference does not filter it (:22-28, :57)
 //   4. loss      = sum_r rowsum[r] / (R*nf)  (kl_div reduction='mean'); 0 if R == 0 (:19-20)
 #include "common.h"
 
 #define DPL_WAVES 4
+
+// (sum of v[0 .. first), sum of v[0 .. n)) by the whole 256-thread block, in every thread: what a block needs of the
+// exclusive scan of the keep flags (the rank of its first row, the number of kept rows) without a scan kernel in between.
+// Integer sums: any order gives the same result.
+__device__ __forceinline__ int2 dpl_block_counts(const int *__restrict__ v, int first, int n) {
+    __shared__ int part[2][4];
+    int before = 0, all = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int x = v[i];
+        all += x;
+        before += i < first ? x : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_xor(before, o);
+        all += __shfl_xor(all, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = before;
+        part[1][threadIdx.x >> 6] = all;
+    }
+    __syncthreads();
+    return make_int2(part[0][0] + part[0][1] + part[0][2] + part[0][3], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+}
+// rank of row `row` (kept rows before it) from the block's first-row rank
+__device__ __forceinline__ int dpl_rank_of(const int *__restrict__ keep, int first_rank, int first, int row) {
+    int r = first_rank;
+    for (int i = first; i < row; ++i) r += keep[i];
+    return r;
+}
 
 __global__ __launch_bounds__(256) void dpl_keep_kernel(const float *__restrict__ w1, int n, int nf, int blender,
                                                        int *__restrict__ keep) {
@@ -26,41 +57,19 @@ __global__ __launch_bounds__(256) void dpl_keep_kernel(const float *__restrict__
 }
 
 // exclusive scan of keep[0..n) by ONE 1024-thread block (n <= a few 10^4 rows per chunk)
-__global__ __launch_bounds__(1024) void dpl_scan_kernel(const int *__restrict__ keep, int n, int *__restrict__ rank,
-                                                        int *__restrict__ total) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = tid * per, hi = min(n, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += keep[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int base = tid > 0 ? part[tid - 1] : 0;
-    for (int i = lo; i < hi; ++i) {
-        rank[i] = base;
-        base += keep[i];
-    }
-    if (tid == 1023) *total = part[1023];
-}
 
 __global__ __launch_bounds__(256) void dpl_rows_kernel(
     const float *__restrict__ t1, const float *__restrict__ t0, const float *__restrict__ w1,
     const float *__restrict__ w0, const float *__restrict__ mus0, const float *__restrict__ sig0,
     const float *__restrict__ left0, const float *__restrict__ part0, int n, int nc, int nf,
-    const int *__restrict__ keep, const int *__restrict__ rank, float *__restrict__ rowsum) {
+    const int *__restrict__ keep, float *__restrict__ rowsum) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * DPL_WAVES + wave;
+    const int2 cnt = dpl_block_counts(keep, blockIdx.x * DPL_WAVES, n);
     const bool live = row < n && keep[row < n ? row : 0];
     const size_t i = live ? row : 0;
-    const int r = live ? rank[i] : 0;
+    const int r = live ? dpl_rank_of(keep, cnt.x, blockIdx.x * DPL_WAVES, row) : 0;
     float *p0 = smem + (size_t)wave * (2 * nc + 3 * nf + 2);  // [nc]
     float *cdf = p0 + nc;                                         // [nc+1]
     float *p1 = cdf + nc + 1;                                     // [nf]
@@ -138,11 +147,21 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
 // mean over the kept rows in a fixed order (thread t owns rows t, t+1024, ...; then an LDS tree), and -- when the caller
 // passes the DD head's scalars -- the level-1 `dp_loss` record of the reference, dp * nf + mus_reg + sig_reg
 // (models/models.py:287-289), in the same launch.
-__global__ __launch_bounds__(1024) void dpl_finish_kernel(const float *__restrict__ rowsum, const int *__restrict__ total, int nf,
+__global__ __launch_bounds__(1024) void dpl_finish_kernel(const float *__restrict__ rowsum, const int *__restrict__ keep, int n, int nf,
                                                          float *__restrict__ loss, const float *__restrict__ reg_scal,
                                                          float *__restrict__ loss_total) {
     __shared__ double part[1024];
-    const int R = *total, tid = threadIdx.x;
+    __shared__ int cnt[1024];
+    const int tid = threadIdx.x;
+    int c = 0;
+    for (int i = tid; i < n; i += 1024) c += keep[i];
+    cnt[tid] = c;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) cnt[tid] += cnt[tid + o];
+        __syncthreads();
+    }
+    const int R = cnt[0];  // kept rows
     double s = 0.0;
     for (int r = tid; r < R; r += 1024) s += (double)rowsum[r];
     part[tid] = s;
@@ -167,19 +186,17 @@ DDN_EXPORT int ddnerf_dp_loss_forward(const float *t1, const float *t0, const fl
     DDN_REQUIRE(t1 && t0 && w1 && w0 && mus0 && sig0 && left0 && part0 && loss && workspace, DDNERF_E_ARG);
     DDN_REQUIRE((reg_scal == nullptr) == (loss_total == nullptr), DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && nc > 0 && nf > 0, DDNERF_E_ARG);
-    int *keep = (int *)workspace, *rank = keep + n;
-    float *rowsum = (float *)(rank + n);
-    int *total = (int *)(rowsum + n);
+    int *keep = (int *)workspace;
+    float *rowsum = (float *)(keep + 2 * n);  // (workspace layout of ddnerf_dp_loss_workspace_bytes: n flags, n spare, n row sums)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((n + DPL_WAVES - 1) / DPL_WAVES);
     hipLaunchKernelGGL(dpl_keep_kernel, grid, dim3(256), (size_t)DPL_WAVES * nf * sizeof(float), st, w1, n, nf, blender,
                        keep);
-    hipLaunchKernelGGL(dpl_scan_kernel, dim3(1), dim3(1024), 0, st, keep, n, rank, total);
     size_t lds = (size_t)DPL_WAVES * (2 * nc + 3 * nf + 2) * sizeof(float);
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
     hipLaunchKernelGGL(dpl_rows_kernel, grid, dim3(256), lds, st, t1, t0, w1, w0, mus0, sig0, left0, part0, n, nc, nf,
-                       keep, rank, rowsum);
-    hipLaunchKernelGGL(dpl_finish_kernel, dim3(1), dim3(1024), 0, st, rowsum, total, nf, loss, reg_scal, loss_total);
+                       keep, rowsum);
+    hipLaunchKernelGGL(dpl_finish_kernel, dim3(1), dim3(1024), 0, st, rowsum, keep, n, nf, loss, reg_scal, loss_total);
     return ddn_launch_status();
 }
 
@@ -198,15 +215,16 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
     const float *__restrict__ t1, const float *__restrict__ t0, const float *__restrict__ w1,
     const float *__restrict__ w0, const float *__restrict__ mus0, const float *__restrict__ sig0,
     const float *__restrict__ left0, const float *__restrict__ part0, int n, int nc, int nf,
-    const int *__restrict__ keep, const int *__restrict__ rank, const int *__restrict__ total,
+    const int *__restrict__ keep,
     const float *__restrict__ g_loss, float *__restrict__ g_w0, float *__restrict__ g_mus, float *__restrict__ g_sig) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * DPL_WAVES + wave;
     const bool inrange = row < n;
+    const int2 cnt = dpl_block_counts(keep, blockIdx.x * DPL_WAVES, n);  // (rank of the block's first row, kept rows)
     const bool live = inrange && keep[inrange ? row : 0];
     const size_t i = inrange ? row : 0;
-    const int r = live ? rank[i] : 0;
+    const int r = live ? dpl_rank_of(keep, cnt.x, blockIdx.x * DPL_WAVES, row) : 0;
     const int nf1 = nf + 1;
     float *p0 = smem + (size_t)wave * DPLB_WORDS(nc, nf);  // [nc]
     float *cdf = p0 + nc;                                  // [nc+1]
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
     if (live)
         for (int m = lane; m < nf; m += 64) p1sum += p1[m];
     for (int o = 32; o > 0; o >>= 1) p1sum += __shfl_xor(p1sum, o);
-    const float gscale = live ? g_loss[0] / ((float)(*total) * (float)nf) : 0.0f;
+    const float gscale = live ? g_loss[0] / ((float)cnt.y * (float)nf) : 0.0f;
     __syncthreads();
     if (live)
         for (int m = lane; m < nf; m += 64) {  // l = sum_m xlogy(p,p) - p log q,  q = (d+eps)/se
@@ -372,18 +390,16 @@ DDN_EXPORT int ddnerf_dp_loss_backward(const float *t1, const float *t0, const f
     DDN_REQUIRE(t1 && t0 && w1 && w0 && mus0 && sig0 && left0 && part0 && g_loss && g_w0 && g_mus && g_sig && workspace,
                 DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && nc > 0 && nf > 0, DDNERF_E_ARG);
-    int *keep = (int *)workspace, *rank = keep + n;
-    float *rowsum = (float *)(rank + n);
-    int *total = (int *)(rowsum + n);
+    int *keep = (int *)workspace;
+    float *rowsum = (float *)(keep + 2 * n);  // (workspace layout of ddnerf_dp_loss_workspace_bytes: n flags, n spare, n row sums)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((n + DPL_WAVES - 1) / DPL_WAVES);
-    // keep / rank / total are recomputed (cheap) so the backward does not depend on the forward's workspace
+    // the keep flags are recomputed (cheap) so the backward does not depend on the forward's workspace
     hipLaunchKernelGGL(dpl_keep_kernel, grid, dim3(256), (size_t)DPL_WAVES * nf * sizeof(float), st, w1, n, nf, blender,
                        keep);
-    hipLaunchKernelGGL(dpl_scan_kernel, dim3(1), dim3(1024), 0, st, keep, n, rank, total);
     size_t lds = (size_t)DPL_WAVES * DPLB_WORDS(nc, nf) * 4;
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
     hipLaunchKernelGGL(dpl_rows_bwd_kernel, grid, dim3(256), lds, st, t1, t0, w1, w0, mus0, sig0, left0, part0, n, nc, nf,
-                       keep, rank, total, g_loss, g_w0, g_mus, g_sig);
+                       keep, g_loss, g_w0, g_mus, g_sig);
     return ddn_launch_status();
 }
