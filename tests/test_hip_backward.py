@@ -130,6 +130,11 @@ def test_mlp_backward_vs_autograd(ops, depth, M, mlp_dtype):
     from ddnerf_amd import functions as F
     from ddnerf_amd import base_architectures as BA
 
+    if M % 128:  # ragged: the records the kernels are about to allocate come out of NaN-filled memory -- pad columns (samples
+        # M .. ld) and rows nobody writes must not leak into a weight gradient
+        ld = (M + 127) // 128 * 128
+        poison = [torch.full((2560, ld), float("nan"), device="cuda") for _ in range(3)] + [torch.full((160, ld), -1, dtype=torch.int16, device="cuda")]
+        del poison
     g = torch.Generator().manual_seed(5)
     net = (BA.DepthMipNeRFModel if depth else BA.MipNeRFModel)(hidden_size=256, include_input_dir=True)
     sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(depth, 9, 3.0).items()}
@@ -209,9 +214,12 @@ def test_train_step_gradients_match_reference(name):
         assert float((a - b).norm()) <= (3e-2 if chaotic else 1e-2) * float(b.norm()), (pfx, float((a - b).norm() / b.norm()))
 
 
-def test_forward_sees_optimizer_updates(ops):
+@pytest.mark.parametrize("fused", [False, True])
+def test_forward_sees_optimizer_updates(ops, fused):
     """Regression (stale packed-weight cache): after an Adam step the fused forward must evaluate the UPDATED weights --
-    compared with a fresh module loaded from the updated state_dict and with the fp32 torch restatement."""
+    compared with a fresh module loaded from the updated state_dict and with the fp32 torch restatement.  torch's fused Adam
+    (what TrainStepper uses on the GPU) updates parameters WITHOUT bumping their version counters: the cache tag carries an
+    optimiser-step epoch for it."""
     from ddnerf_amd import base_architectures as ba
     import torch_ref
 
@@ -219,7 +227,7 @@ def test_forward_sees_optimizer_updates(ops):
     net = ba.DepthMipNeRFModel(include_input_dir=True).cuda()
     feat = torch.zeros(300, 128, device="cuda")
     feat[:, :123] = torch.rand(300, 123, device="cuda") * 2 - 1
-    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, **({"fused": True} if fused else {}))
     raw0 = net(feat)
     raw0.square().mean().backward()
     opt.step()
