@@ -90,6 +90,16 @@ __device__ inline float ddn_aten_sum(const float *x, int n) {
     return acc;
 }
 
+// Barrier for LDS data that only ONE wave touches (the wave-per-ray kernels keep a region per wave): a wave's LDS operations
+// execute in order, so all it takes is that the compiler neither moves accesses across this point nor keeps values in
+// registers over it -- no s_barrier, the block's other waves run on.  (__syncthreads at these places made every wave of a
+// 256-thread block wait for the slowest at each of up to 40 points per ray.)
+__device__ __forceinline__ void ddn_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Same order, but the 8 vector lanes are 8 GPU lanes (lane l < 8 owns vector lane l); the final
 // lane-0..7 chain runs on lane 0 after a gather.  Used where a whole wave is available.
 __device__ inline float ddn_aten_sum_wave(const float *x, int n, int lane) {

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             }
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live && lane == 0) {  // exclusive cumprod, double accumulator, fp32 prefixes
         double p = 1.0;
         for (int j = 0; j < S; ++j) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             p *= (double)x;
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live) {
         for (int j = lane; j < S; j += 64) {
             float w = alpha[j] * trans[j];                              // :43
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             weights[(size_t)ray * S + j] = w2;
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     float c_sum = 0.0f;
     if (live && lane < 3) {  // rgb_map = sum_j w_j * rgb_j, j ascending (:47-48)
         for (int j = 0; j < S; ++j) c_sum = c_sum + wpre[j] * rgbs[3 * j + lane];
@@ -84,15 +84,15 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             tmp[j] = pdf * ((t[j + 1] + t[j]) / 2.0f);                  // :19, :66
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     float dm = ddn_aten_sum_wave(tmp, S, lane);                         // :68
-    __syncthreads();
+    ddn_wave_sync();
     float cdm = 0.0f;
     if (mus) {                                                          // :77-83
         if (live)
             for (int j = lane; j < S; j += 64)
                 tmp[j] = alpha[j] * (t[j] + mus[(size_t)ray * S + j] * (t[j + 1] - t[j]));
-        __syncthreads();
+        ddn_wave_sync();
         cdm = ddn_aten_sum_wave(tmp, S, lane);
     }
     if (live) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             alpha[j] = a;
             trans[j] = 1.0f - a + 1e-10f;
         }
-    __syncthreads();
+    ddn_wave_sync();
     if (live && lane == 0) {  // same transmittance arithmetic as the forward kernel
         double p = 1.0;
         for (int j = 0; j < S; ++j) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             p *= (double)x;
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live)
         for (int j = lane; j < S; j += 64) {
             const size_t m = r0 * S + j;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             g[2] = G2 * w * 1.002f * s2 * (1.0f - s2);
             for (int k = 4; k < ldr; ++k) g[k] = 0.0f;
         }
-    __syncthreads();
+    ddn_wave_sync();
     // exclusive suffix sum of suf[] by the wave: chunks of 64 from the back, carry across chunks
     float carry = 0.0f;
     const int nchunk = (S + 63) / 64;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         if (live && j < S) suf[j] = excl;
         carry += __shfl(inc, 0);
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live)
         for (int j = lane; j < S; j += 64) {
             const size_t m = r0 * S + j;

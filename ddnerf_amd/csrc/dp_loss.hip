@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void dpl_keep_kernel(const float *__restrict__
     float *buf = smem + (size_t)wave * nf;
     if (live)
         for (int j = lane; j < nf; j += 64) buf[j] = w1[(size_t)row * nf + j];
-    __syncthreads();
+    ddn_wave_sync();
     float s = ddn_aten_sum_wave(buf, nf, lane);
     if (live && lane == 0) keep[row] = blender ? (s > 1e-10f ? 1 : 0) : 1;
 }
@@ -84,14 +84,14 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
         for (int j = lane; j < nc; j += 64) p0[j] = w0[i * nc + j] + eps;
         for (int j = lane; j < nf; j += 64) p1[j] = w1[i * nf + j] + eps;
     }
-    __syncthreads();
+    ddn_wave_sync();
     float s0 = ddn_aten_sum_wave(p0, nc, lane);                       // :31
     float s1 = ddn_aten_sum_wave(p1, nf, lane);                       // :32
     if (live) {
         for (int j = lane; j < nc; j += 64) p0[j] = p0[j] / s0;
         for (int j = lane; j < nf; j += 64) p1[j] = p1[j] / s1;
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live && lane == 0) {  // torch.cumsum order (double running sum), clamp at 1      :38-41
         double a = 0.0;
         cdf[0] = 0.0f;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
         }
         cdf[nc] = 1.0f;
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live) {
         for (int m = lane; m <= nf; m += 64) {
             const float tm = T1[m];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
             est[m] = e;
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     // estimated_pdf_1 = clamp(diff, 0) + eps, renormalised                                      :68-72
     if (live)
         for (int m = lane; m < nf; m += 64) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
             if (dlt < 0.0f) dlt = 0.0f;                                // :70
             e1[m] = dlt + eps;
         }
-    __syncthreads();
+    ddn_wave_sync();
     float se = ddn_aten_sum_wave(e1, nf, lane);                       // :72
     float acc = 0.0f;
     if (live)
@@ -256,14 +256,14 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
         for (int j = lane; j < nc; j += 64) p0[j] = w0[i * nc + j] + eps;
         for (int j = lane; j < nf; j += 64) p1[j] = w1[i * nf + j] + eps;
     }
-    __syncthreads();
+    ddn_wave_sync();
     const float s0 = ddn_aten_sum_wave(p0, nc, lane);
     const float s1 = ddn_aten_sum_wave(p1, nf, lane);
     if (live) {
         for (int j = lane; j < nc; j += 64) p0[j] = p0[j] / s0;
         for (int j = lane; j < nf; j += 64) p1[j] = p1[j] / s1;
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live && lane == 0) {
         double a = 0.0;
         cdf[0] = 0.0f;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
         cdf[nc] = 1.0f;
         gcdf[nc] = 0.0f;
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live)
         for (int m = lane; m <= nf; m += 64) {
             const float tm = T1[m];
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
             cMu[m] = dedx * (-1.0f / sr) * seclen;   // x = (t - mr)/sr, mr = T0 + mu*seclen
             cSg[m] = dedx * (-x / sr) * seclen;      // sr = sg*seclen
         }
-    __syncthreads();
+    ddn_wave_sync();
     if (live)
         for (int m = lane; m < nf; m += 64) {
             float dlt = est[m + 1] - est[m];
@@ -313,20 +313,20 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
             dq[m] = (pos ? dlt : 0.0f) + eps;
             dpos[m] = pos;
         }
-    __syncthreads();
+    ddn_wave_sync();
     const float se = ddn_aten_sum_wave(dq, nf, lane);
     float p1sum = 0.0f;
     if (live)
         for (int m = lane; m < nf; m += 64) p1sum += p1[m];
     for (int o = 32; o > 0; o >>= 1) p1sum += __shfl_xor(p1sum, o);
     const float gscale = live ? g_loss[0] / ((float)cnt.y * (float)nf) : 0.0f;
-    __syncthreads();
+    ddn_wave_sync();
     if (live)
         for (int m = lane; m < nf; m += 64) {  // l = sum_m xlogy(p,p) - p log q,  q = (d+eps)/se
             float q = dq[m] / se;
             dq[m] = dpos[m] ? gscale * (p1sum - p1[m] / q) / se : 0.0f;
         }
-    __syncthreads();
+    ddn_wave_sync();
     if (live)
         for (int m = lane; m <= nf; m += 64) {
             float g = 0.0f;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
             if (m < nf) g -= dq[m];
             ge[m] = eclamp[m] ? 0.0f : g;
         }
-    __syncthreads();
+    ddn_wave_sync();
     if (live)
         for (int j = lane; j <= nc; j += 64) {  // d/d cdf[j] = sum over the (contiguous) m with k_m == j
             int lo = 0, hi = nf1;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
             for (int m = lo; m <= nf && kk[m] == j; ++m) acc += ge[m];
             gcdf[j] = acc * gcdf[j];  // zero for cdf[0], cdf[nc] and the clamped prefixes
         }
-    __syncthreads();
+    ddn_wave_sync();
     if (live && lane == 0) {  // cdf[k] = sum_{j<k} p0[j]  ->  d/d p0[j] += sum_{k>j} gcdf[k]
         float run = 0.0f;
         for (int j = nc - 1; j >= 0; --j) {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
             gp0[j] = run;
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     if (live)
         for (int j = lane; j < nc; j += 64) {  // per-bin sums over the (contiguous) m with ki_m == j
             int lo = 0, hi = nf1;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void dpl_rows_bwd_kernel(
             g_mus[i * nc + j] = b;
             g_sig[i * nc + j] = c;
         }
-    __syncthreads();
+    ddn_wave_sync();
     float dot = 0.0f;  // p0 = (w0+eps)/s0  ->  g_w0_j = (gp0_j - sum_i gp0_i p0_i) / s0
     if (live)
         for (int j = lane; j < nc; j += 64) dot += gp0[j] * p0[j];
@@ -391,7 +391,6 @@ DDN_EXPORT int ddnerf_dp_loss_backward(const float *t1, const float *t0, const f
                 DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && nc > 0 && nf > 0, DDNERF_E_ARG);
     int *keep = (int *)workspace;
-    float *rowsum = (float *)(keep + 2 * n);  // (workspace layout of ddnerf_dp_loss_workspace_bytes: n flags, n spare, n row sums)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((n + DPL_WAVES - 1) / DPL_WAVES);
     // the keep flags are recomputed (cheap) so the backward does not depend on the forward's workspace

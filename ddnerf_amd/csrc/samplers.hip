@@ -22,11 +22,11 @@ __device__ __forceinline__ void build_cdf(const float *__restrict__ w, int nc, i
             wp[j] = v;
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     float sum = ddn_aten_sum_wave(wp, nc, lane);                             // :87 torch.sum order
     if (live)
         for (int j = lane; j < nc; j += 64) wp[j] = wp[j] / sum;             // pdf
-    __syncthreads();
+    ddn_wave_sync();
     if (live && lane == 0) {  // torch.cumsum: double running sum, fp32 prefixes; clamp at 1   :88-91
         double a = 0.0;
         cdf[0] = 0.0f;
@@ -36,7 +36,7 @@ __device__ __forceinline__ void build_cdf(const float *__restrict__ w, int nc, i
         }
         cdf[nc] = 1.0f;
     }
-    __syncthreads();
+    ddn_wave_sync();
 }
 
 // k = last j in [0,len) with cdf[j] <= u  (mask = u >= cdf[j] is a prefix because cdf is non-decreasing)
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void sample_pdf_mu_sigma_kernel(
             out[s] = v;
         }
     }
-    __syncthreads();
+    ddn_wave_sync();
     // torch.sort(dim=1): bitonic network, ascending
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void sample_pdf_mu_sigma_kernel(
                     }
                 }
             }
-            __syncthreads();
+            ddn_wave_sync();
         }
     }
     if (live)
