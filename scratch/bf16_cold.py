@@ -41,3 +41,20 @@ print("events, encode between       %.4f ms" % per_launch(lambda: ops.encode(ray
 def idle():
     torch.cuda.synchronize()
 print("events, sync (idle) between  %.4f ms" % per_launch(idle))
+# the MLP reading what the encoder has just written (as in a render step)
+rays4 = torch.rand(4096, 12, device="cuda"); rays4[:, 3:6] = torch.nn.functional.normalize(torch.rand(4096, 3, device="cuda") - 0.5, dim=1)
+rays4[:, 9:12] = rays4[:, 3:6]; rays4[:, 6] = 1e-3
+tv4 = torch.sort(torch.rand(4096, 129, device="cuda") * 4 + 2, dim=1)[0].contiguous()
+def chained(reps=30):
+    ts = []
+    for i in range(reps + 5):
+        f = ops.encode(rays4, tv4, cylinder=False, bf16=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.mlp_bf16_forward(f, packed, False); e1.record()
+        ts.append((e0, e1))
+    torch.cuda.synchronize()
+    v = [a.elapsed_time(b) for a, b in ts[5:]]
+    return sum(v) / len(v)
+print("events, MLP on the fresh encoder output  %.4f ms" % chained())
+print("events, encode between (other buffer)    %.4f ms" % per_launch(lambda: ops.encode(rays, tv, cylinder=False, bf16=True)))
+print("events, MLP on the fresh encoder output  %.4f ms" % chained())
