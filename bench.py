@@ -82,29 +82,83 @@ def parse(argv=None):
 
 def rank_environments(n, port):
     """The environment of each of the N ranks the launcher starts (what torch.distributed.run would set, one node)."""
+    # (the collective timeouts end a rank that waits for a dead peer well inside the supervisor's limit)
     return [dict(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                 MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0") for r in range(n)]
+                 MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TORCH_NCCL_ASYNC_ERROR_HANDLING="1",
+                 TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC="300", DDNERF_PG_TIMEOUT_S="300") for r in range(n)]
+
+
+def free_port():
+    """a TCP port nobody listens on right now (bound to port 0 on 127.0.0.1, then released)"""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+RANK_TIMEOUT_S = 540  # the whole N-rank run is bounded below the driver's own 600 s limit
+
+
+def supervise(procs, timeout_s, poll_s=0.2, clock=time.monotonic, sleep=time.sleep):
+    """Wait for every child.  On the first non-zero exit, or when `timeout_s` has passed, terminate (then kill) the others:
+    a rank that died before rendezvous must not leave rank 0 in a collective until the c10d timeout.  Rank 0's stdout is
+    drained by a thread so a chatty child cannot block on a full pipe.  Returns (exit codes, rank 0's stdout, reason)."""
+    import threading
+
+    out = []
+    reader = None
+    if procs and procs[0].stdout is not None:
+        reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+    t0, reason = clock(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            reason = "rank %d exited with code %s" % (bad[0], codes[bad[0]])
+        elif clock() - t0 > timeout_s:
+            reason = "no result after %d s" % timeout_s
+        if reason:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t1 = clock()
+            while any(p.poll() is None for p in procs) and clock() - t1 < 10:
+                sleep(poll_s)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            break
+        sleep(poll_s)
+    if reader is not None:
+        reader.join(timeout=10)
+    return [p.returncode for p in procs], (out[0] if out else ""), reason
 
 
 def launch_ranks(args, argv):
     """--gpus N without a launcher: start the N ranks as child processes, one per GPU (nothing in this process has touched
-    the GPU), relay rank 0's single JSON line and exit with the first non-zero exit code."""
+    the GPU), supervise them (first failure or the time limit ends all of them), relay rank 0's single JSON line and exit
+    non-zero when anything went wrong."""
     import torch
 
     have = torch.cuda.device_count()  # (does not initialise the GPU)
     if have < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
-    port = 29400 + os.getpid() % 2000
+    port = free_port()
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
     procs = []
     for r, env in enumerate(rank_environments(args.gpus, port)):
         procs.append(subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    codes, out, reason = supervise(procs, RANK_TIMEOUT_S)
     lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
-    if any(codes) or len(lines) != 1:
+    if reason or any(codes) or len(lines) != 1:
         sys.stderr.write(out[-4000:])
-        raise SystemExit("bench.py --gpus %d: rank exit codes %s, %d result lines" % (args.gpus, codes, len(lines)))
+        raise SystemExit("bench.py --gpus %d: %s; rank exit codes %s, %d result lines" % (args.gpus, reason or "failed", codes, len(lines)))
     print(lines[0], flush=True)
     raise SystemExit(0)
 
@@ -279,7 +333,10 @@ def main(argv=None):
     if dist:
         import torch.distributed as td
 
-        td.init_process_group("nccl", device_id=device)  # "nccl" IS RCCL on ROCm
+        import datetime
+
+        # "nccl" IS RCCL on ROCm; a bounded collective timeout: a rank whose peer died fails instead of waiting 10 minutes
+        td.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=int(os.environ.get("DDNERF_PG_TIMEOUT_S", "300"))))
         backend = "%s (RCCL)" % td.get_backend()
     from ddnerf_amd import ops, synthetic
 

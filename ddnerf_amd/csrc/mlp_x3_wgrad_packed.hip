@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
         src[t] = (const char *)(in_d ? dT : (in_a2 ? aT2 : aT)) + (size_t)tile0 * 2 * XP_STEP;
         ldst[t] = lds0 + k * 1024;
     }
-    // ragged tail: ld is a multiple of 128 >= M, pad columns of `deltas` are zero words, those of `acts` finite
+    // ragged tail: ld is a multiple of 32 >= M; the pad columns' words are masked below, whatever they hold
     auto issue = [&](int u, int ring_pos) {
         const int uc = min(u, nht - 1);  // past the end: harmless repeats into a slot nobody reads again
         const unsigned slot = (unsigned)ring_pos * SLOT;
@@ -122,17 +122,29 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
         const char *sb = lds_raw + (size_t)rd * SLOT;
         rd = rd + 1 == NS ? 0 : rd + 1;
         wr = wr + 1 == NS ? 0 : wr + 1;
+        // samples of this slot that exist: 16, except in the last granule of a ragged M -- there the words of the samples >= M are
+        // replaced by zeros in BOTH operands (a record's pad columns may hold anything, NaN included: 0 x NaN is NaN)
+        const long nv_l = M - (tile0 * 2 + u) * 16;
+        const int nv = nv_l >= 16 ? 16 : (int)(nv_l > 0 ? nv_l : 0);  // (uniform)
+        const bool ragged = nv < 16;
+        auto frag = [&](const char *p, bf16x8 &fh, bf16x8 &fl) {
+            u32x4 w0 = *(const u32x4 *)(p + o0), w1 = *(const u32x4 *)(p + o1);  // samples 8 h + 0..3 and 8 h + 4..7 of the slot
+            if (ragged) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (8 * h + e >= nv) w0[e] = 0u;
+                    if (8 * h + 4 + e >= nv) w1[e] = 0u;
+                }
+            }
+            xp_unpack(w0, w1, fh, fl);
+        };
         bf16x8 ah[RT], al[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const char *p = sb + (rg * RT + rt) * 32 * 64;
-            xp_unpack(*(const u32x4 *)(p + o0), *(const u32x4 *)(p + o1), ah[rt], al[rt]);
-        }
+        for (int rt = 0; rt < RT; ++rt) frag(sb + (rg * RT + rt) * 32 * 64, ah[rt], al[rt]);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const char *p = sb + (NOP + (cg * CT + ct) * 32) * 64;
             bf16x8 bh, bl;
-            xp_unpack(*(const u32x4 *)(p + o0), *(const u32x4 *)(p + o1), bh, bl);
+            frag(sb + (NOP + (cg * CT + ct) * 32) * 64, bh, bl);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 // small terms first
@@ -146,7 +158,13 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
             for (int r = 0; r < MAXB; ++r) {
                 const int idx = r * THREADS + tid;
                 if ((r + 1) * THREADS <= NBI || idx < NBI) {
-                    const u32x4 w = *(const u32x4 *)(sb + idx * 16);
+                    u32x4 w = *(const u32x4 *)(sb + idx * 16);
+                    if (ragged) {  // LDS chunk (idx & 3) of row idx >> 2 holds source chunk q: samples 4 q .. 4 q + 3 of the slot
+                        const int q = (idx & 3) ^ ((idx >> 4) & 3);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (4 * q + e >= nv) w[e] = 0u;
+                    }
                     bsum[r] += (xp_value(w.x) + xp_value(w.y)) + (xp_value(w.z) + xp_value(w.w));
                 }
             }

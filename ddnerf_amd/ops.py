@@ -178,7 +178,9 @@ def dd_records_launch(weights, mus, sigmas, ssig):
     ws = torch.empty(_lib.lib().ddnerf_dd_records_workspace_bytes(n, nc), dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().ddnerf_dd_records(_ptr(weights), _ptr(mus), _ptr(sigmas), _ptr(ssig), n, nc, *[_ptr(o) for o in outs],
                                             _ptr(total), _ptr(ws), _stream()), "ddnerf_dd_records")
-    ring = _PINNED.setdefault(str(dev), {"slots": [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(8)], "next": 0})
+    ring = _PINNED.get(str(dev))
+    if ring is None:  # (built once per device: a setdefault(...) default would allocate eight pinned tensors on every chunk)
+        ring = _PINNED[str(dev)] = {"slots": [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(8)], "next": 0}
     host = ring["slots"][ring["next"] % 8]
     ring["next"] += 1
     host.copy_(total, non_blocking=True)

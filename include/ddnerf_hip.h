@@ -242,7 +242,8 @@ int ddnerf_mlp_x3_wgrad(const float *deltas, int drow0, int n_out, const float *
  * be a multiple of 32.  max_workgroups (0 = 256) caps the split-K width: with 128, two jobs enqueued on two streams (each
  * with its own workspace) share the chip and write half the partial slabs each.  At the default width the weight gradients
  * are bit-identical to ddnerf_mlp_x3_wgrad on the fp32 matrices the words were split from (another width is another -- equally
- * fixed -- summation order); bias sums add hi + lo (2^-17 relative per term). */
+ * fixed -- summation order); bias sums add hi + lo (2^-17 relative per term).  Only samples 0 .. M - 1 are contracted: the words
+ * of the pad columns M .. ld - 1 are never used, whatever they hold (NaN patterns included). */
 int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
                                 long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
                                 int max_workgroups, ddnerf_stream_t stream);

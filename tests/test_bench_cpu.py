@@ -39,3 +39,47 @@ def test_config_workloads():
     assert (a.rays, a.scaling) == (8192, "weak")
     a = bench.parse(["--config", "config_blender_mipnerf.yml", "--gpus", "2"])
     assert (a.rays, a.mode, a.mlp) == (4096, "both", "fp32")
+
+
+def _child(code):
+    return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
+
+
+def test_supervise_kills_the_siblings_of_a_failed_rank():
+    # rank 1 dies before "rendezvous"; ranks 0 and 2 would wait for it for ten minutes
+    import time
+
+    t0 = time.monotonic()
+    procs = [_child("import time; print('rank0 up', flush=True); time.sleep(600)"),
+             _child("import sys; sys.exit(3)"),
+             _child("import time; time.sleep(600)")]
+    codes, out, reason = bench.supervise(procs, timeout_s=120)
+    assert time.monotonic() - t0 < 30
+    assert codes[1] == 3 and codes[0] != 0 and codes[2] != 0 and all(c is not None for c in codes)
+    assert "rank 1 exited with code 3" in reason and "rank0 up" in out
+
+
+def test_supervise_time_limit_and_success():
+    import time
+
+    t0 = time.monotonic()
+    procs = [_child("import time; time.sleep(600)"), _child("import time; time.sleep(600)")]
+    codes, out, reason = bench.supervise(procs, timeout_s=1.0)
+    assert time.monotonic() - t0 < 30 and "no result after" in reason and all(c not in (None, 0) for c in codes)
+    # a child that ignores SIGTERM is killed
+    procs = [_child("import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); print('x', flush=True); time.sleep(600)")]
+    time.sleep(0.5)
+    codes, out, reason = bench.supervise(procs, timeout_s=0.5)
+    assert codes[0] == -9 and reason
+    # the good case: every rank exits 0, rank 0's output is returned whole (more than a pipe buffer of it)
+    procs = [_child("print('{\"metric\": 1}'); print('y' * 200000)"), _child("pass")]
+    codes, out, reason = bench.supervise(procs, timeout_s=60)
+    assert codes == [0, 0] and reason is None and out.startswith('{"metric": 1}') and len(out) > 200000
+
+
+def test_free_port_is_bindable():
+    import socket
+
+    port = bench.free_port()
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", port))

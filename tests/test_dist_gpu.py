@@ -20,9 +20,17 @@ def _loss(model, cfg, rays):
     return loss + cfg.train_params.dp_coeficient * out[1]["dp_loss"].mean()
 
 
-def _worker(rank, world, port, mlp_dtype, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    td.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, mlp_dtype, q, backend="gloo"):
+    """backend "gloo": every rank on GPU 0; backend "nccl" (= RCCL): rank r on GPU r, the collectives over xGMI"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = rank if backend == "nccl" else 0
+    if backend == "nccl":
+        import datetime
+
+        torch.cuda.set_device(dev)
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev), timeout=datetime.timedelta(seconds=240))
+    else:
+        td.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
         sys.path.insert(0, ROOT)
@@ -30,7 +38,7 @@ def _worker(rank, world, port, mlp_dtype, q):
         from ddnerf_amd.cfgnode import CfgNode
         from models import models
 
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(dev)
         cfg = CfgNode.load(os.path.join(ROOT, "configs", "config_ff.yml"))   # LLFF: no dp-loss row filter
         for mode in ("train", "validation"):
             cfg.nerf[mode].update(num_coarse=16, num_fine=16, perturb=False, radiance_field_noise_std=0.0)
@@ -69,7 +77,8 @@ def _worker(rank, world, port, mlp_dtype, q):
         for _ in range(3):
             loss, _, _ = stepper.step(*shards[rank])
         digest = torch.stack([model.coarse.flat_params().double().sum(), model.fine.flat_params().double().sum(),
-                              model.coarse.flat_params().double().square().sum()]).cpu()
+                              model.coarse.flat_params().double().square().sum()])
+        digest = digest if backend == "nccl" else digest.cpu()
         both = [torch.zeros_like(digest) for _ in range(world)]
         td.all_gather(both, digest)
         ok &= all(bool(torch.equal(b, both[0])) for b in both)
@@ -91,6 +100,33 @@ def test_data_parallel_training_two_ranks_one_gpu(mlp_dtype):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res), res
+
+
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "x3"])
+def test_data_parallel_training_two_gpus_rccl(mlp_dtype):
+    """The same assertions with one rank per GPU over backend "nccl" (RCCL over xGMI): turns itself on wherever the node has
+    two GPUs (the pool's test boxes have one: skipped there)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL across devices)")
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mlp_dtype, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=420) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
     assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res), res
 
 

@@ -58,3 +58,48 @@ def test_split_entry_point_writes_the_documented_layout(ops):
     rec = ops.x3_split(x)
     want = record_of(x.cpu().numpy())
     assert np.array_equal(rec.cpu().numpy().view(np.uint32).reshape(-1), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 17, 33, 1000 - 13, 4096 + 31])
+def test_packed_weight_gradients_ignore_the_pad_columns(ops, M):
+    """ddnerf_mlp_x3_wgrad_packed / _skip contract samples 0 .. M-1 only: records whose pad columns M .. ld-1 hold NaN words
+    (any third-party record, or ddnerf_mlp_x3_split of a torch.empty-padded matrix) give the gradients of the M samples."""
+    from ddnerf_amd import _lib
+
+    ld = (M + 127) // 128 * 128
+    g = torch.Generator(device="cuda").manual_seed(M)
+    acts = torch.randn(ROWS, ld, device="cuda", generator=g)
+    deltas = torch.randn(ROWS, ld, device="cuda", generator=g)
+    acts_nan, deltas_nan = acts.clone(), deltas.clone()
+    acts_nan[:, M:] = float("nan")
+    deltas_nan[:, M:] = float("nan")
+    acts[:, M:] = 0.0
+    deltas[:, M:] = 0.0
+    nws = _lib.lib().ddnerf_mlp_f32_wgrad_workspace_floats(M)
+    ws = torch.empty(nws, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+
+    def run(a, d):
+        ra, rd = ops.x3_split(a), ops.x3_split(d)
+        out = []
+        for (drow0, n_out, arow0, n_in, used) in ((256, 256, 0, 256, 256), (2304, 128, 2048, 256, 256), (512, 3, 2304, 128, 128), (0, 256, 2432, 96, 96)):
+            dst = torch.full((n_out, used), 7.0, device="cuda")
+            db = torch.full((n_out,), 7.0, device="cuda")
+            _lib.check(_lib.lib().ddnerf_mlp_x3_wgrad_packed(P(rd), drow0, n_out, P(ra), arow0, n_in, used, M, ld, P(dst), used, 0, P(db), P(ws), 0, st), "wgrad_packed")
+            out += [dst, db]
+        dst = torch.full((256, 352), 7.0, device="cuda")
+        db = torch.full((256,), 7.0, device="cuda")
+        _lib.check(_lib.lib().ddnerf_mlp_x3_wgrad_packed_skip(P(rd), 1280, P(ra), 2432, 1024, M, ld, P(dst), P(db), P(ws), 0, st), "wgrad_packed_skip")
+        torch.cuda.synchronize()
+        return out + [dst, db]
+
+    clean, dirty = run(acts, deltas), run(acts_nan, deltas_nan)
+    for c, d in zip(clean, dirty):
+        assert torch.isfinite(d).all()
+        assert torch.equal(c, d)
+    # and they are the gradients: fp64 contraction of the first M samples
+    want = deltas[256:512, :M].double() @ acts[0:256, :M].double().T
+    assert float((clean[0].double() - want).abs().max()) <= 1e-4 * float(want.abs().max() + 1)
+    assert float((clean[1].double() - deltas[256:512, :M].double().sum(1)).abs().max()) <= 1e-4 * (1 + M ** 0.5)
