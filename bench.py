@@ -243,8 +243,6 @@ def extra_tier(args, mlp):
     except Exception as e:  # the headline must not die with a tier
         return {"error": "%s: %s" % (type(e).__name__, e)}
     roof = d["roofline"]
-    if roof:
-        roof["fp32_equivalent_tflops"] = round(roof["achieved"] / (3 if mlp == "x3" else 1), 2)
     return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "roofline": roof}
 
 
@@ -262,11 +260,19 @@ def cpu_baseline(args, cfg, sd_c, sd_f):
     t_lin = torch.linspace(0.0, 1.0, args.coarse + 1).numpy()
     u_det = torch.linspace(0.0, 0.9999, args.fine + 1).numpy()
 
+    dd = cfg.nerf.type == "DDNerfModel"
+    mc = cfg.nerf.validation
+    is_blender = str(cfg.dataset.type).lower() == "blender" or str(cfg.dataset.basedir).endswith("segmented")
+    if not dd:  # models/samplers.py:93: the mip sampler's deterministic u includes 1.0
+        u_det = torch.linspace(0.0, 1.0, args.fine + 1).numpy()
+
     def run(n):
-        ro, rd, rad, _ = synthetic.make_rays("blender", n, 1)
+        ro, rd, rad, _ = synthetic.make_rays(args.ray_kind, n, 1)   # this config's ray kind, near / far, dataset branch, sampler
         rng = np.random.default_rng(0)
-        kw = dict(model="dd", nc=args.coarse, nf=args.fine, near=2.0, far=6.0, blender=True, pdf_padding=True,
-                  smooth=1.7, dist_reg=float(cfg.train_params.dist_reg_coeficient), t_lin=t_lin, u_det=u_det,
+        kw = dict(model="dd" if dd else "mip", nc=args.coarse, nf=args.fine, near=float(cfg.dataset.near), far=float(cfg.dataset.far),
+                  blender=is_blender, white_bkgd=bool(mc.white_background), lindisp=bool(mc.lindisp),
+                  pdf_padding=bool(cfg.train_params.pdf_padding), smooth=float(cfg.train_params.gaussian_smooth_factor),
+                  dist_reg=float(cfg.train_params.dist_reg_coeficient), t_lin=t_lin, u_det=u_det,
                   noise0=rng.standard_normal((n, args.coarse)).astype(np.float32),
                   noise1=rng.standard_normal((n, args.fine)).astype(np.float32))
         t0 = time.perf_counter()
@@ -278,7 +284,64 @@ def cpu_baseline(args, cfg, sd_c, sd_f):
     n = int(min(max(args.cpu_rays, args.cpu_rays * 15.0 / max(probe, 1e-3)), 65536)) // 256 * 256
     dt = run(n)
     return {"value": n / dt, "unit": "rays/s", "cores": O.get_threads(), "kind": "port",
-            "sample": "%d rays x (%d+%d) samples, render pass, C oracle with OpenMP, %.1f s" % (n, args.coarse, args.fine, dt)}
+            "sample": "%s, %d %s rays x (%d+%d) samples, render pass, C oracle with OpenMP, %.1f s"
+                      % (args.config, n, args.ray_kind, args.coarse, args.fine, dt)}
+
+
+def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
+    """In-kernel clock and matrix-pipe busy share of the bf16 fine-MLP kernel (MI355X_MICROARCH.md, DVFS give-back item 6):
+    the DIAGNOSTIC build of the same kernel source (ddnerf_amd/csrc/libddnerf_diag.so, -DBF16_STAMP) runs back to back on random
+    bf16 feature rows with this model's fine-network weights for >= `seconds`; every workgroup stamps s_memtime / s_memrealtime
+    around its tile loop.  clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, cycles per 256-sample tile against the 4820 MFMAs x
+    16 cycles the tile needs.  Runs after the timed region; nothing in the product library executes a stamp."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from ddnerf_amd import build as hip_build
+
+    if not os.path.exists(hip_build.DIAG_SO):
+        return None
+    L = C.CDLL(hip_build.DIAG_SO)
+    V = C.c_void_p
+    M = 524288
+    st = torch.cuda.current_stream().cuda_stream
+    fb = (torch.rand(M, 128, device=device) * 2 - 1).to(torch.bfloat16).contiguous()
+    raw = torch.empty(M, 4, device=device)
+    L.ddnerf_mlp_bf16_packed_bytes.restype = C.c_size_t
+    packed = torch.empty(L.ddnerf_mlp_bf16_packed_bytes(0), dtype=torch.uint8, device=device)
+    L.ddnerf_mlp_bf16_pack.argtypes = [V, C.c_int, V, V]
+    f = L.ddnerf_mlp_bf16_forward
+    f.argtypes = [V, V, C.c_int, V, C.c_long, V]
+    L.ddnerf_debug_set_stamps.argtypes = [V]
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    stamps = torch.zeros(n_cu * 5, dtype=torch.int64, device=device)
+    if L.ddnerf_mlp_bf16_pack(flat_params.data_ptr(), 0, packed.data_ptr(), st) or L.ddnerf_debug_set_stamps(stamps.data_ptr()):
+        return None
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds:
+        for _ in range(50):
+            f(fb.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)
+        torch.cuda.synchronize()
+        n += 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        f(fb.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 50
+    s = stamps.cpu().numpy().reshape(n_cu, 5).astype(np.float64)
+    s = s[s[:, 4] > 0]
+    clk = float(np.median((s[:, 2] - s[:, 0]) / (s[:, 3] - s[:, 1]) * 100.0))
+    cyc = float(np.median((s[:, 2] - s[:, 0]) / s[:, 4]))
+    ideal = 4820 * 16
+    return {"in_kernel_clock_mhz": round(clk), "nominal_clock_mhz": 2400, "cycles_per_256_sample_tile": round(cyc), "ideal_cycles_per_tile": ideal,
+            "mfma_busy": round(ideal / cyc, 4), "frac_bound_at_this_clock": round(clk / 2400.0, 4),
+            "back_to_back_launch_ms": round(ms, 4), "back_to_back_frac": round(FLOP_FINE * M / (ms * 1e-3) / 1e12 / PEAK["bf16"], 4),
+            "warm_launches": n, "how": "diagnostic stamp build of the same kernel source, random bf16 feature rows, after the timed region; "
+            "frac ~= mfma_busy x in_kernel_clock / nominal_clock (less launch prologue / tail)"}
 
 
 def kernel_source_digest(mlp):
@@ -395,11 +458,18 @@ def main(argv=None):
         roof = None
         if ms and head == "render":
             traffic, src = measured_traffic(args)
-            ach = (3 if args.mlp == "x3" else 1) * M_fine * FLOP_FINE / (ms * 1e-3) / 1e12
+            # `achieved` / `frac` count ALGORITHMIC FLOP (1,220,608 per sample); the x3 kernel issues three bf16 MFMAs per
+            # product: its issued-work figures stand beside them
+            ach = M_fine * FLOP_FINE / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "mlp_%s_fwd_kernel<fine> (%d samples/launch)" % (args.mlp, M_fine),
                     "achieved": round(ach, 2), "peak": PEAK[args.mlp], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK[args.mlp], 4), "traffic": traffic, "traffic_source": src,
                     "launch_ms": round(ms, 4), "launches_timed": launches}
+            if args.mlp == "x3":
+                roof["issued_tflops"] = round(3 * ach, 2)
+                roof["frac_issued"] = round(3 * ach / PEAK["x3"], 4)
+            if args.mlp == "bf16" and (args.rays, args.fine) == (4096, 128):
+                roof["clock"] = bf16_in_kernel_clock(model.fine.flat_params().detach(), device)
         elif head == "train":
             roof = train_roofline(args, cfg, dt / args.steps)
         net = "DDNerfModel" if cfg.nerf.type == "DDNerfModel" else "GeneralMipNerfModel (one shared MLP)"
@@ -425,7 +495,7 @@ def main(argv=None):
                              "collective": "one all-reduce of the flat fp32 gradient buffer per network per step" if dist else None,
                              "roofline": train_roofline(args, cfg, tdt / args.steps)}
         line.update(tiers)
-        if world == 1 and not args.no_cpu_baseline and args.config == "config_blender.yml":
+        if world == 1 and not args.no_cpu_baseline and head == "render":
             line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f)
         print(json.dumps(line), flush=True)
     if dist:
@@ -444,13 +514,17 @@ def train_roofline(args, cfg, step_s):
     fwd = m_c * f_c + m_f * f_f
     bwd = m_c * (f_c - first) + m_f * (f_f - first)
     wgrad = fwd
+    # algorithmic: every product once, on the unit it runs on; issued: the hi/lo-split passes issue three bf16 MFMAs per product
     if args.mlp == "x3":
-        ideal = 3 * (fwd + bwd + wgrad) / (PEAK["x3"] * 1e12)
+        ideal = (fwd + bwd + wgrad) / (PEAK["x3"] * 1e12)
+        issued = 3 * ideal
     else:
-        ideal = (fwd + bwd) / (PEAK["fp32"] * 1e12) + 3 * wgrad / (PEAK["x3"] * 1e12)
+        ideal = (fwd + bwd) / (PEAK["fp32"] * 1e12) + wgrad / (PEAK["x3"] * 1e12)
+        issued = (fwd + bwd) / (PEAK["fp32"] * 1e12) + 3 * wgrad / (PEAK["x3"] * 1e12)
     return {"bound": "mfma", "kernel": "whole training step (forward + backward-data + weight gradients of both networks)",
             "algorithmic_flop_per_step": fwd + bwd + wgrad, "ideal_ms": round(ideal * 1e3, 4), "step_ms": round(step_s * 1e3, 4),
-            "frac": round(ideal / step_s, 4), "unit": "fraction of the step time the FLOP need at the dense MFMA peaks",
+            "frac": round(ideal / step_s, 4), "frac_issued": round(issued / step_s, 4), "issued_ideal_ms": round(issued * 1e3, 4),
+            "unit": "fraction of the step time the (algorithmic / issued) FLOP need at the dense MFMA peaks",
             "peaks_tflops": {"fp32_mfma": PEAK["fp32"], "bf16_mfma": PEAK["x3"]},
             "note": ("forward / backward-data / weight gradients all as three bf16 MFMAs per product" if args.mlp == "x3" else
                      "forward / backward-data on the fp32 matrix cores, weight gradients as three bf16 MFMAs per product")}

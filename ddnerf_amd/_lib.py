@@ -50,6 +50,12 @@ _SIGS = {
     "ddnerf_mlp_f32_backward_data_rec": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_ray_bundle": (C.c_int, [C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "ddnerf_ndc_depth_to_regular": (C.c_int, [C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "ddnerf_pack_rays_first_cycle": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "ddnerf_dd_coarse_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddnerf_dd_coarse_forward": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [c_fp] * 20),
+    "ddnerf_composite_forward_keep": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int] + [c_fp] * 8),
+    "ddnerf_dp_loss_forward_kept": (C.c_int, [c_fp] * 8 + [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_mlp_f32_wgrad_workspace_floats": (C.c_size_t, [C.c_long]),
     "ddnerf_mlp_f32_wgrad": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
                                        C.c_int, C.c_int, c_fp, c_fp, c_fp]),
@@ -58,6 +64,10 @@ _SIGS = {
     "ddnerf_mlp_x3_wgrad_packed": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
                                               C.c_int, C.c_int, c_fp, c_fp, C.c_int, c_fp]),
     "ddnerf_mlp_x3_wgrad_packed_skip": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_long, C.c_long, c_fp, c_fp, c_fp, C.c_int, c_fp]),
+    "ddnerf_mlp_x3_wgrad_pairs": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
+                                            C.c_int, C.c_int, c_fp, c_fp, C.c_int, c_fp]),
+    "ddnerf_mlp_x3_wgrad_pairs_skip": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_long, C.c_long, c_fp, c_fp, c_fp, C.c_int, c_fp]),
+    "ddnerf_mlp_x3_split_pairs": (C.c_int, [c_fp, C.c_int, C.c_long, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_x3_split": (C.c_int, [c_fp, C.c_int, C.c_long, C.c_int, c_fp, c_fp]),
 }
 

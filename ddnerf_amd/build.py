@@ -66,6 +66,23 @@ def _compile_checked(cmd, src, obj, kernel, verbose):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# Diagnostic build of the bf16 MLP kernel (-DBF16_STAMP: every workgroup stamps s_memtime / s_memrealtime around its tile loop
+# into a buffer of its own).  bench.py loads it AFTER its timed region to report the in-kernel clock and the matrix-pipe busy
+# share beside the roofline fraction; the product library never contains a stamp.
+DIAG_SO = os.path.join(CSRC, "libddnerf_diag.so")
+
+
+def build_diag(force: bool = False, verbose: bool = False) -> str:
+    deps = [os.path.join(CSRC, f) for f in ("mlp_bf16.hip", "mlp_mfma16.inc", "mlp_bf16_common.h", "common.h", "api.hip")] + [__file__]
+    if force or _stale(DIAG_SO, deps):
+        cmd = [HIPCC] + COMMON + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_STAMP", "-shared", os.path.join(CSRC, "mlp_bf16.hip"),
+                                  os.path.join(CSRC, "api.hip"), "-o", DIAG_SO]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return DIAG_SO
+
+
 def _stale(target, deps):
     return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
@@ -89,11 +106,15 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
-    if todo:  # the two big MFMA kernels take about a minute each: compile the translation units side by side
+    if todo:  # the big MFMA kernels take about a minute each: compile the translation units side by side
         from concurrent.futures import ThreadPoolExecutor
 
-        with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 1, 8)) as pool:
+        with ThreadPoolExecutor(max_workers=jobs or min(len(todo) + 1, os.cpu_count() or 1, 8)) as pool:
+            diag = pool.submit(build_diag, force, verbose)
             list(pool.map(run, todo))
+            diag.result()
+    else:
+        build_diag(force, verbose)
     if force or _stale(SO, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
     return SO

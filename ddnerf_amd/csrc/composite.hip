@@ -15,24 +15,39 @@
 // ---------------------------------------------------------------------------------------------------
 #define COMP_WAVES 4
 
+// HEAD (the coarse pass of DDNerfModel, render path): the same launch also evaluates the DD head of its rays (dd_head_kernel's
+// arithmetic, element for element; `raw` has 6 columns, `mus` is an OUTPUT), writes the per-block partial sums of the two L2
+// regularisers and the per-bin flags / per-ray counts of the level-0 records (dd_records_count_kernel's arithmetic: its row sum
+// IS this kernel's wsum).  keep_out (the fine pass): the dp loss's row filter torch.sum(w1) > 1e-10 (dpl_keep_kernel: again wsum).
+struct HeadOut {
+    float *mus, *sigmas, *left, *part, *ssig, *sleft, *spart, *partials;
+    unsigned char *rec_flags;
+    int *rec_counts;
+    float smooth;
+};
+
+template <bool HEAD>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float *__restrict__ raw, int ldr, const float *__restrict__ t_vals, const float *__restrict__ rays,
     const float *__restrict__ noise, const float *__restrict__ mus, int n, int S, int flags,
     float *__restrict__ rgb_map, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
-    float *__restrict__ depth, float *__restrict__ cdisp, float *__restrict__ rgb_out) {
+    float *__restrict__ depth, float *__restrict__ cdisp, float *__restrict__ rgb_out, int *__restrict__ keep_out, HeadOut ho) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ray = blockIdx.x * COMP_WAVES + wave;
     const bool live = ray < n;
-    float *alpha = smem + (size_t)wave * 8 * S;  // [S]
+    constexpr int NARR = HEAD ? 9 : 8;
+    float *alpha = smem + (size_t)wave * NARR * S;  // [S]
     float *trans = alpha + S;                    // [S]  (1-alpha+1e-10), then exclusive transmittance
     float *wpre = trans + S;                     // [S]  weights before the blender epsilon
     float *wpost = wpre + S;                     // [S]  returned weights
     float *tmp = wpost + S;                      // [S]
     float *rgbs = tmp + S;                       // [3S]
+    float *musl = rgbs + 3 * S;                  // [S]  HEAD: the head's mus of this ray
     const bool white = flags & DDNERF_COMP_WHITE_BKGD, blender = flags & DDNERF_COMP_BLENDER;
     const float *t = t_vals + (size_t)(live ? ray : 0) * (S + 1);
 
+    float sq_m = 0.0f, sq_s = 0.0f;
     if (live) {
         const float *d = rays + 12 * (size_t)ray + 3;
         const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);  // :23
@@ -50,6 +65,41 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
                 rgbs[3 * j + k] = c;
                 if (rgb_out) rgb_out[m * 3 + k] = c;
             }
+            if constexpr (HEAD) {  // models/models.py:242-260, 266-273 (dd_head_kernel)
+                const float rm = r[4], rs = r[5];
+                const float mu = ddn_sigmoid(rm), sg = ddn_sigmoid(rs) + 0.001f;
+                ho.mus[m] = mu;
+                musl[j] = mu;
+                ho.sigmas[m] = sg;
+                sq_m = sq_m + fabsf(rm) * fabsf(rm);
+                sq_s = sq_s + fabsf(rs) * fabsf(rs);
+                const float l = ddn_norm_cdf((0.0f - mu) / sg);
+                ho.left[m] = l;
+                ho.part[m] = ddn_norm_cdf((1.0f - mu) / sg) - l;
+                const float ss = sg * ho.smooth;
+                ho.ssig[m] = ss;
+                const float sl = ddn_norm_cdf((0.0f - mu) / ss);
+                ho.sleft[m] = sl;
+                ho.spart[m] = ddn_norm_cdf((1.0f - mu) / ss) - sl;
+            }
+        }
+    }
+    if constexpr (HEAD) {  // per-block partial sums of the regularisers: dd_head_kernel's 256-thread tree (at S = 64 the very same
+        // 256 elements on the same threads: bit-identical partials); they are added up by the records kernel that follows
+        __shared__ float red[2][256];
+        red[0][threadIdx.x] = sq_m;
+        red[1][threadIdx.x] = sq_s;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + st];
+                red[1][threadIdx.x] += red[1][threadIdx.x + st];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            ho.partials[2 * blockIdx.x] = red[0][0];
+            ho.partials[2 * blockIdx.x + 1] = red[1][0];
         }
     }
     ddn_wave_sync();
@@ -77,6 +127,18 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
         for (int j = 0; j < S; ++j) c_sum = c_sum + wpre[j] * rgbs[3 * j + lane];
     }
     float wsum = ddn_aten_sum_wave(wpost, S, lane);                     // :58 and :70 (same operand)
+    if constexpr (HEAD) {  // models/models.py:292-295 (dd_records_count_kernel): bins with w / sum(w) > 0.1
+        if (live) {
+            int cnt = 0;
+            for (int j = lane; j < S; j += 64) {
+                const int f = (wpost[j] / wsum) > 0.1f;  // NaN (an all-zero row) compares false, like torch
+                ho.rec_flags[(size_t)ray * S + j] = (unsigned char)f;
+                cnt += f;
+            }
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (lane == 0) ho.rec_counts[ray] = cnt;
+        }
+    }
     if (live) {
         for (int j = lane; j < S; j += 64) {
             float pdf = blender ? wpost[j] / wsum : wpost[j];           // :58 / :61
@@ -88,10 +150,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     float dm = ddn_aten_sum_wave(tmp, S, lane);                         // :68
     ddn_wave_sync();
     float cdm = 0.0f;
-    if (mus) {                                                          // :77-83
+    const bool has_mus = HEAD || mus != nullptr;
+    if (has_mus) {                                                      // :77-83
         if (live)
-            for (int j = lane; j < S; j += 64)
-                tmp[j] = alpha[j] * (t[j] + mus[(size_t)ray * S + j] * (t[j + 1] - t[j]));
+            for (int j = lane; j < S; j += 64) {
+                const float mu = HEAD ? musl[j] : mus[(size_t)ray * S + j];
+                tmp[j] = alpha[j] * (t[j] + mu * (t[j + 1] - t[j]));
+            }
         ddn_wave_sync();
         cdm = ddn_aten_sum_wave(tmp, S, lane);
     }
@@ -100,12 +165,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
         if (lane == 0) {
             acc[ray] = wsum;
             disp[ray] = 1.0f / fmaxf(1e-10f, dm / wsum);                // :71
-            if (mus) {
+            if (has_mus) {
                 if (cdisp) cdisp[ray] = 1.0f / fmaxf(1e-10f, cdm / wsum);  // :82
                 depth[ray] = cdm;                                       // :83
             } else {
                 depth[ray] = dm;
             }
+            // models/dd_utils.py:16 (dpl_keep_kernel): the filter applies to dataset type "blender" only -- its own flag bit
+            if (keep_out) keep_out[ray] = (flags & DDNERF_COMP_DP_FILTER) ? (wsum > 1e-10f ? 1 : 0) : 1;
         }
     }
 }
@@ -119,9 +186,25 @@ DDN_EXPORT int ddnerf_composite_forward(const float *raw, int ldr, const float *
     DDN_REQUIRE(ldr >= 4, DDNERF_E_RANGE);
     size_t lds = (size_t)COMP_WAVES * 8 * S * sizeof(float);
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);  // S <= 512
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds,
+    hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds,
                        (hipStream_t)stream, raw, ldr, t_vals, rays, noise, mus, n, S, flags, rgb_map, disp, acc,
-                       weights, depth, cdisp, rgb);
+                       weights, depth, cdisp, rgb, (int *)nullptr, HeadOut{});
+    return ddn_launch_status();
+}
+
+// The fine pass of DDNerfModel (render path): compositing + the dp loss's row filter in one launch.  keep [n] int32 is the
+// first array of a ddnerf_dp_loss_workspace_bytes(n) workspace, handed to ddnerf_dp_loss_forward_kept.
+DDN_EXPORT int ddnerf_composite_forward_keep(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
+                                             const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc,
+                                             float *weights, float *depth, float *cdisp, void *dp_workspace, ddnerf_stream_t stream) {
+    DDN_REQUIRE(raw && t_vals && rays && rgb_map && disp && acc && weights && depth && dp_workspace, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ldr >= 4, DDNERF_E_RANGE);
+    size_t lds = (size_t)COMP_WAVES * 8 * S * sizeof(float);
+    DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
+    hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds, (hipStream_t)stream, raw, ldr,
+                       t_vals, rays, noise, mus, n, S, flags, rgb_map, disp, acc, weights, depth, cdisp, (float *)nullptr,
+                       (int *)dp_workspace, HeadOut{});
     return ddn_launch_status();
 }
 
@@ -383,13 +466,37 @@ __global__ __launch_bounds__(256) void dd_records_count_kernel(const float *__re
 
 // Every block finds the output offset of its own rays by counting what the rays in front of it keep (integer sums over the
 // count kernel's per-ray counts: no scan launch in between); the block that owns the last ray also writes the total.
+// (One block more than the rays need, when `partials` is given: its first wave adds up the regulariser partial sums the fused
+// coarse kernel left behind -- dd_head_finish_kernel's arithmetic -- into scal[4].)
 __global__ __launch_bounds__(256) void dd_records_write_kernel(const unsigned char *__restrict__ flags,
                                                               const int *__restrict__ counts, const float *__restrict__ mus,
                                                               const float *__restrict__ sigmas, const float *__restrict__ ssig,
                                                               int n, int nc, float *__restrict__ out_mus,
                                                               float *__restrict__ out_sigmas, float *__restrict__ out_ssig,
-                                                              int *__restrict__ total) {
+                                                              int *__restrict__ total, const float *__restrict__ partials,
+                                                              int npartials, float dist_reg, float *__restrict__ scal) {
     __shared__ int part[4];
+    if (partials && blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x < 64) {
+            double m = 0.0, s2 = 0.0;
+            for (int b = threadIdx.x; b < npartials; b += 64) {
+                m += (double)partials[2 * b];
+                s2 += (double)partials[2 * b + 1];
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                m += __shfl_down(m, o);
+                s2 += __shfl_down(s2, o);
+            }
+            if (threadIdx.x == 0) {
+                float ml = (float)m / (float)n, sl = (float)s2 / (float)n;
+                scal[0] = ml;
+                scal[1] = sl;
+                scal[2] = dist_reg * ml;
+                scal[3] = dist_reg * sl;
+            }
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ray = blockIdx.x * 4 + wave;
     const int first = blockIdx.x * 4;
     int before = 0;
@@ -432,6 +539,41 @@ DDN_EXPORT int ddnerf_dd_records(const float *weights, const float *mus, const f
     dim3 grid((unsigned)((n + 3) / 4));
     hipLaunchKernelGGL(dd_records_count_kernel, grid, dim3(256), 0, st, weights, n, nc, flags, counts);
     hipLaunchKernelGGL(dd_records_write_kernel, grid, dim3(256), 0, st, flags, counts, mus, sigmas, ssig, n, nc, out_mus,
-                       out_sigmas, out_ssig, total);
+                       out_sigmas, out_ssig, total, (const float *)nullptr, 0, 0.0f, (float *)nullptr);
+    return ddn_launch_status();
+}
+
+// The coarse pass of DDNerfModel behind the MLP, render path (models/models.py:242-295), as TWO launches instead of five:
+//   1. the DD head (ddnerf_dd_head), the compositing with the head's mus (ddnerf_composite_forward) and the flags / counts of
+//      the level-0 records, wave per ray;
+//   2. the records' ordered writes (ddnerf_dd_records) and the regularisers' final sums -> scal[4].
+// Outputs are bit for bit those of the three separate entry points at nc = 64 (the regulariser partial sums cover the same 256
+// elements per block; another nc is another -- equally fixed -- summation order).  workspace:
+// ddnerf_dd_coarse_workspace_bytes(n, nc).
+DDN_EXPORT size_t ddnerf_dd_coarse_workspace_bytes(int n, int nc) {
+    if (n <= 0 || nc <= 0) return 0;
+    return ddnerf_dd_records_workspace_bytes(n, nc) + 16 + 2 * sizeof(float) * (size_t)((n + COMP_WAVES - 1) / COMP_WAVES);
+}
+
+DDN_EXPORT int ddnerf_dd_coarse_forward(const float *raw6, const float *t_vals, const float *rays, const float *noise, int n, int nc,
+                                        int flags, float smooth, float dist_reg, float *mus, float *sigmas, float *left,
+                                        float *part, float *ssig, float *sleft, float *spart, float *scal, float *rgb_map,
+                                        float *disp, float *acc, float *weights, float *depth, float *cdisp, float *rec_mus,
+                                        float *rec_sigmas, float *rec_ssig, int *rec_total, void *workspace, ddnerf_stream_t stream) {
+    DDN_REQUIRE(raw6 && t_vals && rays && mus && sigmas && left && part && ssig && sleft && spart && scal, DDNERF_E_ARG);
+    DDN_REQUIRE(rgb_map && disp && acc && weights && depth && cdisp && rec_mus && rec_sigmas && rec_ssig && rec_total && workspace, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    size_t lds = (size_t)COMP_WAVES * 9 * nc * sizeof(float);
+    DDN_REQUIRE(lds <= 60 * 1024, DDNERF_E_RANGE);
+    hipStream_t st = (hipStream_t)stream;
+    int *counts = (int *)workspace, *offsets = counts + n;
+    unsigned char *rflags = (unsigned char *)(offsets + n + 1);
+    const int nblocks = (n + COMP_WAVES - 1) / COMP_WAVES;
+    float *partials = (float *)(((size_t)(rflags + (size_t)n * nc) + 15) & ~(size_t)15);
+    HeadOut ho = {mus, sigmas, left, part, ssig, sleft, spart, partials, rflags, counts, smooth};
+    hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(nblocks), dim3(256), lds, st, raw6, 6, t_vals, rays, noise, (const float *)nullptr, n,
+                       nc, flags, rgb_map, disp, acc, weights, depth, cdisp, (float *)nullptr, (int *)nullptr, ho);
+    hipLaunchKernelGGL(dd_records_write_kernel, dim3((unsigned)((n + 3) / 4 + 1)), dim3(256), 0, st, rflags, counts, mus, sigmas, ssig, n, nc,
+                       rec_mus, rec_sigmas, rec_ssig, rec_total, partials, nblocks, dist_reg, scal);
     return ddn_launch_status();
 }

@@ -200,6 +200,27 @@ DDN_EXPORT int ddnerf_dp_loss_forward(const float *t1, const float *t0, const fl
     return ddn_launch_status();
 }
 
+// The same with the row filter already in the workspace (ddnerf_composite_forward_keep wrote keep[0..n) while it composited the
+// fine pass: torch.sum(w1) is that kernel's wsum): two launches instead of three.
+DDN_EXPORT int ddnerf_dp_loss_forward_kept(const float *t1, const float *t0, const float *w1, const float *w0,
+                                           const float *mus0, const float *sig0, const float *left0, const float *part0,
+                                           int n, int nc, int nf, float *loss, const float *reg_scal, float *loss_total,
+                                           void *workspace, ddnerf_stream_t stream) {
+    DDN_REQUIRE(t1 && t0 && w1 && w0 && mus0 && sig0 && left0 && part0 && loss && workspace, DDNERF_E_ARG);
+    DDN_REQUIRE((reg_scal == nullptr) == (loss_total == nullptr), DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0 && nf > 0, DDNERF_E_ARG);
+    int *keep = (int *)workspace;
+    float *rowsum = (float *)(keep + 2 * n);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((n + DPL_WAVES - 1) / DPL_WAVES);
+    size_t lds = (size_t)DPL_WAVES * (2 * nc + 3 * nf + 2) * sizeof(float);
+    DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
+    hipLaunchKernelGGL(dpl_rows_kernel, grid, dim3(256), lds, st, t1, t0, w1, w0, mus0, sig0, left0, part0, n, nc, nf,
+                       keep, rowsum);
+    hipLaunchKernelGGL(dpl_finish_kernel, dim3(1), dim3(1024), 0, st, rowsum, keep, n, nf, loss, reg_scal, loss_total);
+    return ddn_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K5b  backward of estimate_dp_loss w.r.t. (w0, mus0, sig0) -- the only differentiable inputs at the call site
 // (models/models.py:287-288: every other argument is .detach()ed).  The discrete choices (row filter, bin

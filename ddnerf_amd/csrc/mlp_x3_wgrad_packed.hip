@@ -42,6 +42,8 @@ __device__ __forceinline__ void xp_unpack(const u32x4 w0, const u32x4 w1, bf16x8
 __device__ __forceinline__ float xp_value(unsigned w) {
     return __builtin_bit_cast(float, w & 0xffff0000u) + __builtin_bit_cast(float, w << 16);
 }
+__device__ __forceinline__ float xp_hi16(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ float xp_lo16(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 
 #ifndef XP_NS_BIG
 #define XP_NS_BIG 5
@@ -50,14 +52,22 @@ template <int ROWS> constexpr int xp_nslot() { return ROWS * 64 * 8 <= 160 * 102
 
 // NINA > 0: the activation rows come from TWO row ranges of the record, the first NINA from aT, the others from aT2 (layers_xyz.5
 // contracts its deltas over cat(xyz, h4): rows 2432.. and rows 1024..; one pass over the deltas instead of two jobs)
-template <int RT, int CT, int RG, int CG, bool BIAS, int NINA = 0>
+// PAIRS: the operands are records of bf16 ROW PAIRS (the x3 training tier, include/ddnerf_hip.h: ddnerf_mlp_x3_wgrad_pairs): one
+// 32-bit word holds bf16(row 2p) | bf16(row 2p + 1) << 16 of one sample, a record row is a row PAIR; every product is ONE MFMA.
+// Everything is the same kernel on half as many LDS rows (a lane's row is the low or the high half of its pair's words: one
+// v_perm_b32 selector per lane); a bias item sums both rows of its pair.
+template <int RT, int CT, int RG, int CG, bool BIAS, int NINA = 0, bool PAIRS = false>
 __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned *__restrict__ dT, const unsigned *__restrict__ aT,
                                                                   const unsigned *__restrict__ aT2, long M, long ld, int tiles_per_wg,
                                                                   float *__restrict__ slabs, float *__restrict__ bias_slabs) {
-    constexpr int NOP = 32 * RT * RG, NIN = 32 * CT * CG, NW = RG * CG, THREADS = 64 * NW, ROWS = NOP + NIN;
+    constexpr int RPW = PAIRS ? 2 : 1;  // operand rows per LDS row
+    constexpr int NOP = 32 * RT * RG, NIN = 32 * CT * CG, NW = RG * CG, THREADS = 64 * NW, ROWS = (NOP + NIN) / RPW;
+    constexpr int NOPL = NOP / RPW, NINAL = NINA / RPW, TILE_LR = 32 / RPW;  // LDS rows of the deltas / of the first range / of a 32-row tile
     constexpr int NI = ROWS / 16, IPW = (NI + NW - 1) / NW;  // transfer instructions per slot / per wave (surplus ones repeat the last)
     constexpr int SLOT = ROWS * 64, NS = xp_nslot<ROWS>();
-    constexpr int NBI = NOP * 4, MAXB = (NBI + THREADS - 1) / THREADS;  // bias items (row, chunk) per slot / per thread
+    constexpr int STEP_BYTES = XP_STEP / RPW;                // bytes from one 16-sample block of the record to the next
+    constexpr int NBI = NOPL * 4, MAXB = (NBI + THREADS - 1) / THREADS;  // bias items (LDS row, chunk) per slot / per thread
+    static_assert(NOPL % 16 == 0 && NINAL % 16 == 0 && ROWS % 16 == 0, "whole 16-row transfers");
     static_assert((NS - 2) * IPW <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,9 +85,11 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.0f;
-    float bsum[MAXB];
+    float bsum[MAXB][RPW];
 #pragma unroll
-    for (int r = 0; r < MAXB; ++r) bsum[r] = 0.0f;
+    for (int r = 0; r < MAXB; ++r)
+#pragma unroll
+        for (int e = 0; e < RPW; ++e) bsum[r][e] = 0.0f;
 
     // transfer i of this wave: rows 16k .. 16k+15 of the slot, k = wave + NW i (clamped: a surplus transfer repeats the last
     // one, same data to the same place, so that every wave issues IPW per slot and one vmcnt value certifies a slot)
@@ -89,10 +101,10 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
         const int k = min(wave + NW * t, NI - 1);                      // (uniform)
         const int row = 16 * k + (lane >> 2);
         const int q = (lane & 3) ^ ((lane >> 4) & 3);                  // source chunk of LDS chunk (lane & 3): (row >> 2) & 3 swizzle
-        const bool in_d = 16 * k < NOP;                                // (uniform; NOP is a multiple of 16)
-        const bool in_a2 = NINA > 0 && 16 * k >= NOP + NINA;           // (uniform; NINA is a multiple of 16)
-        voff[t] = (unsigned)((in_d ? row : (in_a2 ? row - NOP - NINA : row - NOP)) * 64 + q * 16);
-        src[t] = (const char *)(in_d ? dT : (in_a2 ? aT2 : aT)) + (size_t)tile0 * 2 * XP_STEP;
+        const bool in_d = 16 * k < NOPL;                               // (uniform; NOPL is a multiple of 16)
+        const bool in_a2 = NINA > 0 && 16 * k >= NOPL + NINAL;         // (uniform; NINAL is a multiple of 16)
+        voff[t] = (unsigned)((in_d ? row : (in_a2 ? row - NOPL - NINAL : row - NOPL)) * 64 + q * 16);
+        src[t] = (const char *)(in_d ? dT : (in_a2 ? aT2 : aT)) + (size_t)tile0 * 2 * STEP_BYTES;
         ldst[t] = lds0 + k * 1024;
     }
     // ragged tail: ld is a multiple of 32 >= M; the pad columns' words are masked below, whatever they hold
@@ -101,11 +113,14 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
         const unsigned slot = (unsigned)ring_pos * SLOT;
 #pragma unroll
         for (int t = 0; t < IPW; ++t)
-            asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(src[t] + (size_t)uc * XP_STEP), "{m0}"(ldst[t] + slot)
+            asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(src[t] + (size_t)uc * STEP_BYTES), "{m0}"(ldst[t] + slot)
                          : "memory");
     };
-    const int x = (i >> 2) & 3;
-    const unsigned o0 = i * 64 + (((2 * h) ^ x) * 16), o1 = o0 ^ 16;
+    const int lr = PAIRS ? (i >> 1) : i;  // this lane's LDS row inside a 32-row tile
+    const int x = (lr >> 2) & 3;
+    const unsigned o0 = lr * 64 + (((2 * h) ^ x) * 16), o1 = o0 ^ 16;
+    const unsigned half_sel = (i & 1) ? 0x07060302u : 0x05040100u;  // PAIRS: odd rows sit in the high halves of the pair's words
+    (void)half_sel;
 
     if (nht > 0) {
 #pragma unroll
@@ -136,21 +151,30 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
                     if (8 * h + 4 + e >= nv) w1[e] = 0u;
                 }
             }
-            xp_unpack(w0, w1, fh, fl);
+            if constexpr (PAIRS) {  // this row's half of the eight words: k = 0..7 of the fragment
+                const u32x4 f = {__builtin_amdgcn_perm(w0.y, w0.x, half_sel), __builtin_amdgcn_perm(w0.w, w0.z, half_sel),
+                                 __builtin_amdgcn_perm(w1.y, w1.x, half_sel), __builtin_amdgcn_perm(w1.w, w1.z, half_sel)};
+                fh = __builtin_bit_cast(bf16x8, f);
+            } else {
+                xp_unpack(w0, w1, fh, fl);
+            }
         };
         bf16x8 ah[RT], al[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) frag(sb + (rg * RT + rt) * 32 * 64, ah[rt], al[rt]);
+        for (int rt = 0; rt < RT; ++rt) frag(sb + (rg * RT + rt) * TILE_LR * 64, ah[rt], al[rt]);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             bf16x8 bh, bl;
-            frag(sb + (NOP + (cg * CT + ct) * 32) * 64, bh, bl);
+            frag(sb + (NOPL + (cg * CT + ct) * TILE_LR) * 64, bh, bl);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                // small terms first
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][ct], 0, 0, 0);
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][ct], 0, 0, 0);
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][ct], 0, 0, 0);
+                if constexpr (PAIRS) {
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][ct], 0, 0, 0);
+                } else {  // small terms first
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][ct], 0, 0, 0);
+                }
             }
         }
         if (BIAS) {
@@ -165,7 +189,12 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
                         for (int e = 0; e < 4; ++e)
                             if (4 * q + e >= nv) w[e] = 0u;
                     }
-                    bsum[r] += (xp_value(w.x) + xp_value(w.y)) + (xp_value(w.z) + xp_value(w.w));
+                    if constexpr (PAIRS) {  // low halves: the even row, high halves: the odd row
+                        bsum[r][0] += (xp_lo16(w.x) + xp_lo16(w.y)) + (xp_lo16(w.z) + xp_lo16(w.w));
+                        bsum[r][1] += (xp_hi16(w.x) + xp_hi16(w.y)) + (xp_hi16(w.z) + xp_hi16(w.w));
+                    } else {
+                        bsum[r][0] += (xp_value(w.x) + xp_value(w.y)) + (xp_value(w.z) + xp_value(w.w));
+                    }
                 }
             }
         }
@@ -185,29 +214,31 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
 #pragma unroll
         for (int r = 0; r < MAXB; ++r) {
             const int idx = r * THREADS + tid, row = idx >> 2;
-            float s = bsum[r];
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            if ((idx & 3) == 0 && row < NOP) bias_slabs[(size_t)blockIdx.x * NOP + row] = s;
+#pragma unroll
+            for (int e = 0; e < RPW; ++e) {
+                float s = bsum[r][e];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                if ((idx & 3) == 0 && row < NOPL) bias_slabs[(size_t)blockIdx.x * NOP + RPW * row + e] = s;
+            }
         }
     }
 }
 
 static int n_out_pad_of(int n_out) { return n_out > 128 ? 256 : (n_out > 32 ? 128 : 32); }
 
-// Same contract as ddnerf_mlp_x3_wgrad (mlp_x3_wgrad.hip) on the x3 tier's records: `deltas` and `acts` are blocked hi/lo-word
-// records of 2560 rows x ld samples (ld / 16 blocks), as ddnerf_mlp_x3_forward_train / ddnerf_mlp_x3_backward_data write them and as
-// ddnerf_mlp_x3_split produces them from fp32 matrices.
-DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in,
-                                          int n_in_used, long M, long ld, float *dst, int dst_ld, int dst_col0,
-                                          float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
+template <bool PAIRS>
+static int wgrad_packed_impl(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used, long M, long ld,
+                             float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
     DDN_REQUIRE(deltas && acts && dst && workspace, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0 && n_out > 0 && n_out <= 256 && n_in_used > 0 && n_in_used <= n_in, DDNERF_E_ARG);
     DDN_REQUIRE(n_in == 32 || n_in == 96 || n_in == 128 || n_in == 256, DDNERF_E_RANGE);
     DDN_REQUIRE(ld % 32 == 0 && ld >= M, DDNERF_E_RANGE);  // the records hold ld / 16 whole blocks
     DDN_REQUIRE(drow0 >= 0 && arow0 >= 0 && drow0 + n_out_pad_of(n_out) <= XP_ROWS && arow0 + n_in <= XP_ROWS, DDNERF_E_RANGE);
+    DDN_REQUIRE(!PAIRS || (drow0 % 2 == 0 && arow0 % 2 == 0), DDNERF_E_RANGE);  // a record row holds a row PAIR
     DDN_REQUIRE(ddn_aligned(deltas, 16) && ddn_aligned(acts, 16), DDNERF_E_ALIGN);
     hipStream_t st = (hipStream_t)stream;
+    constexpr int RPW = PAIRS ? 2 : 1;
     const int n_out_pad = n_out_pad_of(n_out);
     const long ntiles = (M + XP_TILE - 1) / XP_TILE;
     // split-K width: 256 workgroups fill the chip with ONE job; two jobs side by side on two streams (max_workgroups = 128)
@@ -215,19 +246,19 @@ DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_o
     const int cap = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
     const int nwg = (int)(ntiles < cap ? ntiles : cap);
     const int tiles_per_wg = (int)((ntiles + nwg - 1) / nwg);
-    const unsigned *dT = (const unsigned *)deltas + (size_t)drow0 * 16, *aT = (const unsigned *)acts + (size_t)arow0 * 16;
+    const unsigned *dT = (const unsigned *)deltas + (size_t)(drow0 / RPW) * 16, *aT = (const unsigned *)acts + (size_t)(arow0 / RPW) * 16;
     float *slabs = workspace;
     const size_t slab_stride = (size_t)n_out_pad * n_in;
     float *bias_slabs = dst_bias ? workspace + (size_t)nwg * slab_stride : nullptr;
 #define LAUNCH(RT, CT, RG, CG)                                                                                          \
     do {                                                                                                                \
-        constexpr int ROWS_ = 32 * RT * RG + 32 * CT * CG;                                                              \
+        constexpr int ROWS_ = (32 * RT * RG + 32 * CT * CG) / RPW;                                                      \
         const size_t lds = (size_t)ROWS_ * 64 * xp_nslot<ROWS_>();                                                      \
         if (bias_slabs)                                                                                                 \
-            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, true>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
+            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, true, 0, PAIRS>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
                                tiles_per_wg, slabs, bias_slabs);                                                        \
         else                                                                                                            \
-            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, false>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
+            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, false, 0, PAIRS>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
                                tiles_per_wg, slabs, bias_slabs);                                                        \
     } while (0)
     if (n_out_pad == 256) {
@@ -245,32 +276,63 @@ DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_o
     return ddn_launch_status();
 }
 
-// layers_xyz.5 in ONE job: dst[r * 352 + c] for the 256 rows drow0.. of `deltas` against cat(acts rows arow_a .. +96, acts rows
-// arow_b .. +256) -- the column order of the reference's cat(xyz, h) input -- and the bias sums.
-DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
-                                               float *dst, float *dst_bias, float *workspace, int max_workgroups,
-                                               ddnerf_stream_t stream) {
+template <bool PAIRS>
+static int wgrad_packed_skip_impl(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld, float *dst,
+                                  float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
     DDN_REQUIRE(deltas && acts && dst && dst_bias && workspace, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0 && ld % 32 == 0 && ld >= M, DDNERF_E_RANGE);
     DDN_REQUIRE(drow0 >= 0 && arow_a >= 0 && arow_b >= 0 && drow0 + 256 <= XP_ROWS && arow_a + 96 <= XP_ROWS && arow_b + 256 <= XP_ROWS,
                 DDNERF_E_RANGE);
+    DDN_REQUIRE(!PAIRS || (drow0 % 2 == 0 && arow_a % 2 == 0 && arow_b % 2 == 0), DDNERF_E_RANGE);
     DDN_REQUIRE(ddn_aligned(deltas, 16) && ddn_aligned(acts, 16), DDNERF_E_ALIGN);
     hipStream_t st = (hipStream_t)stream;
+    constexpr int RPW = PAIRS ? 2 : 1;
     const long ntiles = (M + XP_TILE - 1) / XP_TILE;
     const int cap = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
     const int nwg = (int)(ntiles < cap ? ntiles : cap);
     const int tiles_per_wg = (int)((ntiles + nwg - 1) / nwg);
-    const unsigned *dT = (const unsigned *)deltas + (size_t)drow0 * 16;
-    const unsigned *aA = (const unsigned *)acts + (size_t)arow_a * 16, *aB = (const unsigned *)acts + (size_t)arow_b * 16;
-    constexpr int NIN = 352, ROWS = 256 + NIN;
+    const unsigned *dT = (const unsigned *)deltas + (size_t)(drow0 / RPW) * 16;
+    const unsigned *aA = (const unsigned *)acts + (size_t)(arow_a / RPW) * 16, *aB = (const unsigned *)acts + (size_t)(arow_b / RPW) * 16;
+    constexpr int NIN = 352, ROWS = (256 + NIN) / RPW;
     float *slabs = workspace, *bias_slabs = workspace + (size_t)nwg * 256 * NIN;
-    hipLaunchKernelGGL((wgrad_x3p_kernel<1, 11, 8, 1, true, 96>), dim3(nwg), dim3(512), (size_t)ROWS * 64 * xp_nslot<ROWS>(), st, dT, aA, aB, M, ld,
-                       tiles_per_wg, slabs, bias_slabs);
+    hipLaunchKernelGGL((wgrad_x3p_kernel<1, 11, 8, 1, true, 96, PAIRS>), dim3(nwg), dim3(512), (size_t)ROWS * 64 * xp_nslot<ROWS>(), st, dT, aA, aB, M,
+                       ld, tiles_per_wg, slabs, bias_slabs);
     const int total = 256 * NIN, nb_w = (total + 63) / 64, nb_b = (256 + 63) / 64;
     const WgradReduceJob jw = {slabs, (size_t)256 * NIN, NIN, 256, NIN, NIN, 0, dst};
     const WgradReduceJob jb = {bias_slabs, (size_t)256, 1, 256, 1, 1, 0, dst_bias};
     hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3(nb_w + nb_b), dim3(256), 0, st, jw, jb, nb_w, nwg);
     return ddn_launch_status();
+}
+
+// Same contract as ddnerf_mlp_x3_wgrad (mlp_x3_wgrad.hip) on records: `deltas` and `acts` are blocked hi/lo-word records of 2560 rows
+// x ld samples (ld / 16 blocks), as the record-writing build of the fp32 training kernels writes them and as ddnerf_mlp_x3_split
+// produces them from fp32 matrices.
+DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in,
+                                          int n_in_used, long M, long ld, float *dst, int dst_ld, int dst_col0,
+                                          float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
+    return wgrad_packed_impl<false>(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, ld, dst, dst_ld, dst_col0, dst_bias, workspace,
+                                    max_workgroups, stream);
+}
+
+// layers_xyz.5 in ONE job: dst[r * 352 + c] for the 256 rows drow0.. of `deltas` against cat(acts rows arow_a .. +96, acts rows
+// arow_b .. +256) -- the column order of the reference's cat(xyz, h) input -- and the bias sums.
+DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
+                                               float *dst, float *dst_bias, float *workspace, int max_workgroups,
+                                               ddnerf_stream_t stream) {
+    return wgrad_packed_skip_impl<false>(deltas, drow0, acts, arow_a, arow_b, M, ld, dst, dst_bias, workspace, max_workgroups, stream);
+}
+
+// The x3 training tier's weight gradients: the same jobs on records of bf16 ROW PAIRS (what ddnerf_mlp_x3_forward_train and
+// ddnerf_mlp_x3_backward_data write): 1280 pair rows x ld samples, one MFMA per product.  Row offsets are operand rows (even).
+DDN_EXPORT int ddnerf_mlp_x3_wgrad_pairs(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
+                                         long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
+                                         int max_workgroups, ddnerf_stream_t stream) {
+    return wgrad_packed_impl<true>(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, ld, dst, dst_ld, dst_col0, dst_bias, workspace,
+                                   max_workgroups, stream);
+}
+DDN_EXPORT int ddnerf_mlp_x3_wgrad_pairs_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
+                                              float *dst, float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
+    return wgrad_packed_skip_impl<true>(deltas, drow0, acts, arow_a, arow_b, M, ld, dst, dst_bias, workspace, max_workgroups, stream);
 }
 
 // fp32 [rows][ld] ([feature][sample]) -> rows row0 .. row0 + rows - 1 of a blocked hi/lo-word record (mlp_x3_common.h): the
@@ -288,6 +350,27 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float *__restrict__
         o[c] = ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | __builtin_bit_cast(unsigned short, lo);
     }
     *(u32x4 *)(rec + (((size_t)(q >> 2) * XP_ROWS + row0 + row) * 16 + 4 * (q & 3))) = o;
+}
+// fp32 [rows][ld] -> rows row0 .. of a record of bf16 ROW PAIRS: word ((m >> 4) * 1280 + (row >> 1)) * 16 + (m & 15) =
+// bf16(x[row even][m]) | bf16(x[row odd][m]) << 16 (round to nearest even).  rows and row0 even.
+__global__ __launch_bounds__(256) void x3_split_pairs_kernel(const float *__restrict__ x, long ld, int row0, unsigned *__restrict__ rec) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;  // quad of samples
+    const int pr = blockIdx.y;                            // pair of rows
+    if (4 * q >= ld) return;
+    const f32x4 a = *(const f32x4 *)(x + (size_t)(2 * pr) * ld + 4 * q), b = *(const f32x4 *)(x + (size_t)(2 * pr + 1) * ld + 4 * q);
+    u32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        o[c] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a[c]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b[c]) << 16);
+    *(u32x4 *)(rec + (((size_t)(q >> 2) * (XP_ROWS / 2) + row0 / 2 + pr) * 16 + 4 * (q & 3))) = o;
+}
+DDN_EXPORT int ddnerf_mlp_x3_split_pairs(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream) {
+    DDN_REQUIRE(x && record, DDNERF_E_ARG);
+    DDN_REQUIRE(rows > 0 && rows % 2 == 0 && row0 >= 0 && row0 % 2 == 0 && row0 + rows <= XP_ROWS && ld > 0 && ld % 16 == 0, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(x, 16) && ddn_aligned(record, 16), DDNERF_E_ALIGN);
+    hipLaunchKernelGGL(x3_split_pairs_kernel, dim3((unsigned)((ld / 4 + 255) / 256), (unsigned)(rows / 2)), dim3(256), 0, (hipStream_t)stream, x,
+                       ld, row0, (unsigned *)record);
+    return ddn_launch_status();
 }
 DDN_EXPORT int ddnerf_mlp_x3_split(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream) {
     DDN_REQUIRE(x && record, DDNERF_E_ARG);

@@ -91,3 +91,22 @@ DDN_EXPORT int ddnerf_ndc_rays(int H, int W, float focal, float near_, const flo
     hipLaunchKernelGGL(ndc_radii_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, origins_ndc, radii);
     return ddn_launch_status();
 }
+
+// switch_t_ndc_to_regular   data_utils/dataset_helpers.py:45-49 (train_model.py:227-228: the depth maps of an NDC validation
+// pass back in camera-space units).  ro / rd are the REGULAR (un-warped) bundle of the same view; only their z columns are read.
+__global__ void ndc_depth_to_regular_kernel(long n, const float *__restrict__ ndc_depth, const float *__restrict__ ro,
+                                            const float *__restrict__ rd, float *__restrict__ out) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float t = ndc_depth[idx], oz = ro[3 * idx + 2], dz = rd[3 * idx + 2];
+    out[idx] = (t * oz) / (dz - t * dz) + 1.0f;
+}
+
+DDN_EXPORT int ddnerf_ndc_depth_to_regular(long n, const float *ndc_depth, const float *origins, const float *directions, float *depth,
+                                           ddnerf_stream_t stream) {
+    DDN_REQUIRE(ndc_depth && origins && directions && depth, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0, DDNERF_E_ARG);
+    hipLaunchKernelGGL(ndc_depth_to_regular_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, ndc_depth,
+                       origins, directions, depth);
+    return ddn_launch_status();
+}

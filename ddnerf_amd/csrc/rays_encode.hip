@@ -72,6 +72,53 @@ DDN_EXPORT int ddnerf_sample_first_cycle(const float *rays, const float *t_lin, 
     return ddn_launch_status();
 }
 
+// a1 + a2 in one launch (a ray batch that is ONE chunk: the benchmark's and most training batches): thread (ray i, fencepost j)
+// computes t_vals[i][j] from the scalar near / far the packed row would hold, the j = 0 thread also packs row i.  Same
+// arithmetic, same outputs as the two kernels above.
+__global__ void pack_first_cycle_kernel(const float *__restrict__ ro, const float *__restrict__ rd, const float *__restrict__ rad,
+                                        float near_, float far_, const float *__restrict__ t_lin, const float *__restrict__ t_rand,
+                                        float *__restrict__ rays, float *__restrict__ t_vals, int n, int nc, int lindisp) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int s1 = nc + 1;
+    if (idx >= (size_t)n * s1) return;
+    int i = (int)(idx / s1), j = (int)(idx % s1);
+    if (j == 0) {
+        float d0 = rd[3 * i], d1 = rd[3 * i + 1], d2 = rd[3 * i + 2];
+        float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+        float *r = rays + 12 * (size_t)i;
+        r[0] = ro[3 * i]; r[1] = ro[3 * i + 1]; r[2] = ro[3 * i + 2];
+        r[3] = d0; r[4] = d1; r[5] = d2;
+        r[6] = rad[i];
+        r[7] = near_; r[8] = far_;
+        r[9] = d0 / nrm; r[10] = d1 / nrm; r[11] = d2 / nrm;
+    }
+    const float nr = near_, fr = far_;
+    float t = first_cycle_t(nr, fr, t_lin[j], lindisp);
+    if (t_rand) {
+        float lower, upper;
+        if (j == 0) lower = t;
+        else lower = 0.5f * (t + first_cycle_t(nr, fr, t_lin[j - 1], lindisp));
+        if (j == nc) upper = t;
+        else upper = 0.5f * (first_cycle_t(nr, fr, t_lin[j + 1], lindisp) + t);
+        t = lower + (upper - lower) * t_rand[idx];
+        if (j == 0) t = nr;
+        if (j == nc) t = fr;
+    }
+    t_vals[idx] = t;
+}
+
+DDN_EXPORT int ddnerf_pack_rays_first_cycle(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                                            const float *t_lin, const float *t_rand, float *rays, float *t_vals, int n, int nc,
+                                            int lindisp, ddnerf_stream_t stream) {
+    DDN_REQUIRE(origins && directions && radii && t_lin && rays && t_vals, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(lindisp >= 0 && lindisp <= 2, DDNERF_E_RANGE);
+    size_t total = (size_t)n * (nc + 1);
+    hipLaunchKernelGGL(pack_first_cycle_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, origins,
+                       directions, radii, near_, far_, t_lin, t_rand, rays, t_vals, n, nc, lindisp);
+    return ddn_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K1  encode: cast_rays -> conical_frustum_to_gaussian(stable) | cylinder_to_gaussian -> lift_gaussian(diag)
 //     -> integrated_pos_enc(16 octaves) -> cat(view-dir positional encoding)

@@ -94,8 +94,9 @@ class _MLPFunction(torch.autograd.Function):
             feat, acts = ctx.saved_tensors
             packed_t = _cached_pack(net, "fp32_t", ops.mlp_f32_pack_t)
             deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head, rec=ctx.rec)
-        # (records of hi/lo words go to the packed-operand weight-gradient kernel; DDNERF_WGRAD=f32 keeps fp32 matrices)
-        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3p" if (ctx.x3 or ctx.rec) else None)
+        # (the x3 tier's records of bf16 row pairs and the fp32 tier's records of hi/lo words go to the record-operand weight-gradient
+        # kernel; DDNERF_WGRAD=f32 keeps fp32 matrices on the fp32 tier)
+        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3h" if ctx.x3 else ("x3p" if ctx.rec else None))
         net.last_flat_grad = flat_g  # the data-parallel bucket (ddnerf_amd.dist) reduces this buffer
         reducer = getattr(net, "grad_reducer", None)
         if reducer is not None:

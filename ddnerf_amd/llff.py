@@ -12,8 +12,9 @@ Behaviour follows the reference's loader (data_utils/load_llff.py:63-368, itself
   * hold-out view = the camera closest to the average pose                                           (:357-360)
 Pure host-side numpy; images are read with PIL (the reference uses imageio, absent here).  Unlike the reference,
 a missing `images_<factor>` folder is not produced by shelling out to ImageMagick: the full-size images are
-box-filtered down in memory.  The reference cannot be imported in the build container (imageio / cv2 / colmap
-helpers are missing), so this module is covered by property tests only (tests/test_llff_loader.py)."""
+box-filtered down in memory.  Parity: the whole pose pipeline (everything behind the image decoding) is pinned against the
+reference's own outputs on synthetic poses_bounds arrays (tests/golden/loaders.npz, tests/test_loader_parity.py); image
+decoding and folder handling by property tests (tests/test_llff_loader.py).  COLMAP models -> poses_bounds: colmap.py."""
 from __future__ import annotations
 
 import math

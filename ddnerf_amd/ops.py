@@ -178,6 +178,11 @@ def dd_records_launch(weights, mus, sigmas, ssig):
     ws = torch.empty(_lib.lib().ddnerf_dd_records_workspace_bytes(n, nc), dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().ddnerf_dd_records(_ptr(weights), _ptr(mus), _ptr(sigmas), _ptr(ssig), n, nc, *[_ptr(o) for o in outs],
                                             _ptr(total), _ptr(ws), _stream()), "ddnerf_dd_records")
+    return _records_ticket(outs, total, dev)
+
+
+def _records_ticket(outs, total, dev):
+    """the asynchronous copy of the records' length into pinned memory + the event dd_records_finish waits for"""
     ring = _PINNED.get(str(dev))
     if ring is None:  # (built once per device: a setdefault(...) default would allocate eight pinned tensors on every chunk)
         ring = _PINNED[str(dev)] = {"slots": [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(8)], "next": 0}
@@ -218,6 +223,72 @@ def composite_forward(raw, t_vals, rays, noise=None, mus=None, white_bkgd=False,
                                                    _ptr(o["weights"]), _ptr(o["depth"]), _ptr(o["cdisp"]), _ptr(o["rgb"]),
                                                    _stream()), "ddnerf_composite_forward")
     return o
+
+
+def pack_rays_first_cycle(ray_origins, ray_directions, ray_rad, near, far, t_lin, t_rand=None, lindisp=False):
+    """models/models.py:144-162 + models/samplers.py:30-62 in one launch (a ray batch that is one chunk) -> rays [n,12], t_vals [n,nc+1]"""
+    o = _f32c(ray_origins.reshape(-1, 3), "origins")
+    d = _f32c(ray_directions.reshape(-1, 3), "directions")
+    r = _f32c(ray_rad.reshape(-1), "radii")
+    t_lin, t_rand = _f32c(t_lin, "t_lin"), _f32c(t_rand, "t_rand")
+    n, nc = o.shape[0], t_lin.shape[0] - 1
+    rays = torch.empty((n, 12), dtype=torch.float32, device=o.device)
+    t_vals = torch.empty((n, nc + 1), dtype=torch.float32, device=o.device)
+    _lib.check(_lib.lib().ddnerf_pack_rays_first_cycle(_ptr(o), _ptr(d), _ptr(r), float(near), float(far), _ptr(t_lin), _ptr(t_rand),
+                                                       _ptr(rays), _ptr(t_vals), n, nc, int(lindisp), _stream()), "ddnerf_pack_rays_first_cycle")
+    return rays, t_vals
+
+
+def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, blender):
+    """The coarse pass of DDNerfModel behind the MLP, render path (models/models.py:242-295), in two launches: DD head + compositing
+    + level-0 records.  -> (composite dict, head dict, records ticket for dd_records_finish)"""
+    raw6, t_vals, rays, noise = _f32c(raw6, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays"), _f32c(noise, "noise")
+    n, nc, ldr = raw6.shape
+    assert ldr == 6
+    dev = raw6.device
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    head = {k: e(n, nc) for k in ("mus", "sigmas", "left", "part", "ssig", "sleft", "spart")}
+    head["scal"] = e(4)
+    c = dict(rgb_map=e(n, 3), disp=e(n), acc=e(n), weights=e(n, nc), depth=e(n), cdisp=e(n), rgb=None)
+    outs = [e(n * nc) for _ in range(3)]
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.lib().ddnerf_dd_coarse_workspace_bytes(n, nc), dtype=torch.uint8, device=dev)
+    flags = (1 if white_bkgd else 0) | (2 if blender else 0)
+    _lib.check(_lib.lib().ddnerf_dd_coarse_forward(
+        _ptr(raw6), _ptr(t_vals), _ptr(rays), _ptr(noise), n, nc, flags, float(smooth), float(dist_reg),
+        *[_ptr(head[k]) for k in ("mus", "sigmas", "left", "part", "ssig", "sleft", "spart", "scal")],
+        *[_ptr(c[k]) for k in ("rgb_map", "disp", "acc", "weights", "depth", "cdisp")], *[_ptr(o) for o in outs], _ptr(total), _ptr(ws),
+        _stream()), "ddnerf_dd_coarse_forward")
+    return c, head, _records_ticket(outs, total, dev)
+
+
+def composite_forward_keep(raw, t_vals, rays, noise, mus, white_bkgd, blender, dp_filter):
+    """compositing of the fine pass + the dp loss's row filter in one launch -> (composite dict, dp-loss workspace holding keep[n])"""
+    raw, t_vals, rays = _f32c(raw, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays")
+    noise, mus = _f32c(noise, "noise"), _f32c(mus, "mus")
+    n, S, ldr = raw.shape
+    dev = raw.device
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    o = dict(rgb_map=e(n, 3), disp=e(n), acc=e(n), weights=e(n, S), depth=e(n), cdisp=e(n) if mus is not None else None, rgb=None)
+    ws = torch.empty(_lib.lib().ddnerf_dp_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    flags = (1 if white_bkgd else 0) | (2 if blender else 0) | (4 if dp_filter else 0)
+    _lib.check(_lib.lib().ddnerf_composite_forward_keep(_ptr(raw), ldr, _ptr(t_vals), _ptr(rays), _ptr(noise), _ptr(mus), n, S, flags,
+                                                        _ptr(o["rgb_map"]), _ptr(o["disp"]), _ptr(o["acc"]), _ptr(o["weights"]),
+                                                        _ptr(o["depth"]), _ptr(o["cdisp"]), _ptr(ws), _stream()), "ddnerf_composite_forward_keep")
+    return o, ws
+
+
+def dp_loss_forward_kept(t1, t0, w1, w0, mus0, sig0, left0, part0, ws, reg_scal):
+    """dp_loss_forward behind composite_forward_keep (the row filter is in `ws` already) -> (loss, total [1])"""
+    t1, t0, w1, w0, mus0, sig0, left0, part0 = (_f32c(t, "dp_loss arg") for t in (t1, t0, w1, w0, mus0, sig0, left0, part0))
+    n, nc = w0.shape
+    nf = w1.shape[1]
+    loss = torch.empty((), dtype=torch.float32, device=w0.device)
+    total = torch.empty(1, dtype=torch.float32, device=w0.device)
+    _lib.check(_lib.lib().ddnerf_dp_loss_forward_kept(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0), _ptr(part0),
+                                                      n, nc, nf, _ptr(loss), _ptr(_f32c(reg_scal, "reg_scal")), _ptr(total), _ptr(ws), _stream()),
+               "ddnerf_dp_loss_forward_kept")
+    return loss, total
 
 
 def sample_pdf(bins, weights, u_base, rnd, pdf_padding):
@@ -352,13 +423,13 @@ def mlp_x3_pack_t(params_flat, depth_head):
 
 
 def mlp_x3_forward_train(feat, packed, depth_head):
-    """x3 forward that records activations: -> raw [M,4|6], acts = a [2560, ld] record of blocked hi/lo words (x3_unsplit gives
-    the fp32 [feature][sample] matrix), bits [160, ld] uint16 (sign words)"""
+    """x3 forward that records activations: -> raw [M,4|6], acts = a record of bf16 ROW PAIRS, [1280, ld] 32-bit words in a
+    float32-typed tensor (x3_unpair gives the [2560, ld] matrix of the bf16-rounded values), bits [160, ld] uint16 (sign words)"""
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
     ld = (M + 127) // 128 * 128
     raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
-    acts = torch.empty((ACT_ROWS, ld), dtype=torch.float32, device=feat.device)
+    acts = torch.empty((ACT_ROWS // 2, ld), dtype=torch.float32, device=feat.device)
     bits = torch.empty((ACT_ROWS // 32 * 2, ld), dtype=torch.int16, device=feat.device)
 
     def launch():
@@ -373,11 +444,11 @@ def mlp_x3_forward_train(feat, packed, depth_head):
 
 
 def mlp_x3_backward_data(g_raw, packed_t, bits, depth_head):
-    """-> deltas: a [2560, ld] record of blocked hi/lo words, like mlp_x3_forward_train's acts"""
+    """-> deltas: a record of bf16 row pairs ([1280, ld] words), like mlp_x3_forward_train's acts"""
     g_raw = _f32c(g_raw, "g_raw")
     M = g_raw.shape[0]
     ld = bits.shape[1]
-    deltas = torch.empty((ACT_ROWS, ld), dtype=torch.float32, device=g_raw.device)
+    deltas = torch.empty((ACT_ROWS // 2, ld), dtype=torch.float32, device=g_raw.device)
     _lib.check(_lib.lib().ddnerf_mlp_x3_backward_data(_ptr(g_raw), _ptr(packed_t), _ptr(bits), int(depth_head), _ptr(deltas),
                                                       M, ld, _stream()), "ddnerf_mlp_x3_backward_data")
     return deltas
@@ -407,11 +478,25 @@ def ndc_rays(H, W, focal, origins, directions, near=1.0):
     return o, d, r
 
 
+def ndc_depth_to_regular(ndc_depth, origins, directions):
+    """data_utils/dataset_helpers.py:45-49 (switch_t_ndc_to_regular): NDC depth map [H,W] + the regular bundle [H,W,3] x 2 of
+    the same view -> camera-space depth [H,W]"""
+    ndc_depth, origins, directions = _f32c(ndc_depth, "ndc_depth"), _f32c(origins, "origins"), _f32c(directions, "directions")
+    assert origins.shape == directions.shape == tuple(ndc_depth.shape) + (3,)
+    out = torch.empty_like(ndc_depth)
+    _lib.check(_lib.lib().ddnerf_ndc_depth_to_regular(ndc_depth.numel(), _ptr(ndc_depth), _ptr(origins), _ptr(directions), _ptr(out),
+                                                      _stream()), "ddnerf_ndc_depth_to_regular")
+    return out
+
+
 # weight-gradient arithmetic: "x3" = bf16 matrix cores with exact hi/lo operand splits (3 MFMAs per product, ~2^-16
 # relative product error, HBM-bound); "f32" = the fp32 matrix cores (exact fp32 products, MFMA-bound, 3x slower)
 # "x3p" = the same three-MFMA product on operands that already hold hi/lo words (what the x3 training kernels record)
 WGRAD_MODE = os.environ.get("DDNERF_WGRAD", "x3")
-_WGRAD_FN = {"x3": "ddnerf_mlp_x3_wgrad", "f32": "ddnerf_mlp_f32_wgrad", "x3p": "ddnerf_mlp_x3_wgrad_packed"}
+# "x3h" = ONE MFMA per product on records of bf16 row pairs (the x3 training tier: its forward / backward-data chains stay fp32-class,
+# the weight gradients contract bf16-rounded activations and deltas with fp32 accumulation -- half the record bytes, a third of the MFMAs)
+_WGRAD_FN = {"x3": "ddnerf_mlp_x3_wgrad", "f32": "ddnerf_mlp_f32_wgrad", "x3p": "ddnerf_mlp_x3_wgrad_packed", "x3h": "ddnerf_mlp_x3_wgrad_pairs"}
+_RECORD_MODES = ("x3p", "x3h")
 
 
 WGRAD_PAIRED = os.environ.get("DDNERF_WGRAD_PAIRED", "1") != "0"
@@ -435,6 +520,26 @@ def x3_split(x):
     return w
 
 
+def x3_split_pairs(x):
+    """fp32 [2560, ld] ([feature][sample]) -> a record of bf16 row pairs ([1280, ld] words in a float32-typed tensor): word
+    ((m >> 4) * 1280 + (row >> 1)) * 16 + (m & 15) = bf16(x[row even][m]) | bf16(x[row odd][m]) << 16"""
+    x = _f32c(x, "x")
+    assert x.shape[0] == ACT_ROWS and x.shape[1] % 16 == 0
+    w = torch.empty((ACT_ROWS // 2, x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ddnerf_mlp_x3_split_pairs(_ptr(x), x.shape[0], x.shape[1], 0, _ptr(w), _stream()), "ddnerf_mlp_x3_split_pairs")
+    return w
+
+
+def x3_unpair(rec):
+    """a record of bf16 row pairs ([1280, ld] words) -> fp32 [2560, ld]: the bf16 values it holds"""
+    ld = rec.shape[1]
+    i = rec.view(torch.int32).view(ld // 16, ACT_ROWS // 2, 16).permute(1, 0, 2).reshape(ACT_ROWS // 2, ld)
+    out = torch.empty((ACT_ROWS, ld), dtype=torch.float32, device=rec.device)
+    out[0::2] = (i << 16).view(torch.float32)
+    out[1::2] = (i & -65536).view(torch.float32)
+    return out
+
+
 def x3_unsplit(rec):
     """a record of the x3 training tier -> fp32 [2560, ld] values hi + lo (differs from the recorded value by <= 2^-17 relative)"""
     ld = rec.shape[1]
@@ -447,14 +552,15 @@ def mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, dst
     """dst[r*dst_ld + dst_col0 + c] = sum_s deltas[drow0+r][s] * acts[arow0+c][s]; dst_bias[r] = sum_s deltas[drow0+r][s]"""
     mode = mode or WGRAD_MODE
     fn = getattr(_lib.lib(), _WGRAD_FN[mode])
-    extra = (int(max_wg),) if mode == "x3p" else ()
+    extra = (int(max_wg),) if mode in _RECORD_MODES else ()
     _lib.check(fn(_ptr(deltas), drow0, n_out, _ptr(acts), arow0, n_in, n_in_used, M, deltas.shape[1], _ptr(dst), dst_ld,
                   dst_col0, _ptr(dst_bias), _ptr(workspace), *extra, _stream()), _WGRAD_FN[mode])
 
 
 def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
     """all parameter gradients of one network -> (flat gradient buffer in registration order, per-parameter views).
-    mode "x3p": acts / deltas are the x3 training kernels' records (blocked hi/lo words)."""
+    mode "x3p": acts / deltas are records of blocked hi/lo words (the fp32 tier's record build); "x3h": records of bf16 row pairs
+    (the x3 training kernels')."""
     params = list(net.parameters())
     flat_g = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=acts.device)
     off, gv, views = 0, {}, []
@@ -465,7 +571,8 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
         off += p.numel()
     nws = _lib.lib().ddnerf_mlp_f32_wgrad_workspace_floats(M)
     main = torch.cuda.current_stream()
-    pair = mode == "x3p" and WGRAD_PAIRED
+    records = mode in _RECORD_MODES
+    pair = records and WGRAD_PAIRED
     if pair:
         # two half-width jobs side by side (each fills half the CUs: one workgroup per CU): half the partial slabs per job, and
         # one job's prologue / slab epilogue / reduction under the other's main loop
@@ -489,13 +596,13 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
         w, b = gv["layers_xyz.%d.weight" % l], gv["layers_xyz.%d.bias" % l]
         if l == 0:
             job(0, 256, ROW_X, 96, 96, w, 96, 0, b)
-        elif l == 5 and mode == "x3p":  # cat(xyz, h4) in one pass over the deltas
+        elif l == 5 and records:  # cat(xyz, h4) in one pass over the deltas
             st, ws = lanes[turn[0] % len(lanes)]
             turn[0] += 1
+            skip = _WGRAD_FN[mode] + "_skip"
             with torch.cuda.stream(st):
-                _lib.check(_lib.lib().ddnerf_mlp_x3_wgrad_packed_skip(_ptr(deltas), 1280, _ptr(acts), ROW_X, 1024, M, deltas.shape[1], _ptr(w),
-                                                                      _ptr(b), _ptr(ws), 128 if pair else 0, _stream()),
-                           "ddnerf_mlp_x3_wgrad_packed_skip")
+                _lib.check(getattr(_lib.lib(), skip)(_ptr(deltas), 1280, _ptr(acts), ROW_X, 1024, M, deltas.shape[1], _ptr(w),
+                                                     _ptr(b), _ptr(ws), 128 if pair else 0, _stream()), skip)
         elif l == 5:
             job(1280, 256, ROW_X, 96, 96, w, 352, 0, b)
             job(1280, 256, 1024, 256, 256, w, 352, 96, None)
@@ -503,7 +610,7 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
             job(256 * l, 256, 256 * (l - 1), 256, 256, w, 256, 0, b)
     job(ROW_FEAT, 256, 256 * 7, 256, 256, gv["fc_feat.weight"], 256, 0, gv["fc_feat.bias"])
     wd = gv["layers_dir.0.weight"]
-    if mode == "x3p":
+    if records:
         # Jobs that contract over the same activations share ONE pass over them (rows ROW_DIR .. ROW_X + 5 of `deltas` are
         # adjacent: d(dir hidden) 128 rows, then d(raw): 0..2 rgb, 3 alpha, 4..5 mu / sigma):
         #   [d(dir hidden) ; d(raw)] x fc_feat out  -> the dir layer's hidden columns and fc_alpha   (saves 288 - 32 rows x M)

@@ -89,3 +89,14 @@ def make_rays(kind: str, n: int, seed: int):
 
 
 NEAR_FAR = {"blender": (2.0, 6.0), "llff": (0.0, 1.0), "real360": (0.2, 2.8)}
+
+
+def procedural_targets(o, d):
+    """A smooth analytic colour per ray (a function of the camera position and the unit viewing direction): targets a network can
+    actually fit, for the training-parity trajectory (tests/golden/make_golden.py gen_train300; SURVEY.md 8d "PSNR vs ref (2)")."""
+    o = np.asarray(o, np.float64)
+    u = np.asarray(d, np.float64)
+    u = u / np.linalg.norm(u, axis=-1, keepdims=True)
+    ph = 2.0 * u * np.array([1.0, 2.0, 3.0]) + o * np.array([0.7, 0.5, 0.3])
+    rgb = 0.5 + 0.4 * np.sin(ph) * np.cos(ph[:, [1, 2, 0]] * 0.5)
+    return rgb.astype(np.float32)

@@ -62,6 +62,11 @@ int ddnerf_pack_rays(const float *origins, const float *directions, const float 
  * get_combined_samples (models/samplers.py:6-27, dataset.combined_sampling_method). */
 int ddnerf_sample_first_cycle(const float *rays, const float *t_lin, const float *t_rand, float *t_vals, int n, int nc,
                               int lindisp, ddnerf_stream_t stream);
+/* a1 + a2 in ONE launch for a ray batch that is a single chunk: rays [n,12] and t_vals [n,nc+1], bit for bit the outputs of
+ * ddnerf_pack_rays followed by ddnerf_sample_first_cycle. */
+int ddnerf_pack_rays_first_cycle(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                                 const float *t_lin, const float *t_rand, float *rays, float *t_vals, int n, int nc, int lindisp,
+                                 ddnerf_stream_t stream);
 
 /* a3+a4+a5  cast_rays -> integrated_pos_enc, positional_encoding(view dirs), concat
  * general_utils/math_utils.py:7-166, general_utils/nerf_helpers.py:127-171, models/models.py:124-133
@@ -98,11 +103,13 @@ int ddnerf_mlp_x3_pack(const float *params, int depth_head, void *packed, ddnerf
 int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head, float *raw, long M,
                           ddnerf_stream_t stream);
 
-/* x3 training kernels (same network, same accuracy class): the forward that records what the backward needs, the W^T
- * images, and the fused backward-data pass -- drop-ins for ddnerf_mlp_f32_forward_train / _pack_t / _backward_data.
+/* x3 training kernels (same network; forward and backward-data chains in the same accuracy class): the forward that records what
+ * the backward needs, the W^T images, and the fused backward-data pass -- drop-ins for ddnerf_mlp_f32_forward_train / _pack_t /
+ * _backward_data.
  *   packed: the inference kernel's weight image (ddnerf_mlp_x3_pack): the training forward is the same kernel plus the records
- *   acts  a RECORD of ddnerf_mlp_act_rows() rows x ld samples (row map as for the fp32 kernels; ld = M rounded up to 128) in
- *         "blocked hi/lo words" -- see ddnerf_mlp_x3_wgrad_packed, the kernel that reads it -- NOT an fp32 matrix
+ *   acts  a RECORD of ddnerf_mlp_act_rows() rows x ld samples (row map as for the fp32 kernels; ld = M rounded up to 128) as
+ *         "bf16 row pairs": ddnerf_mlp_act_rows() / 2 * ld 32-bit words -- see ddnerf_mlp_x3_wgrad_pairs, the kernel that reads
+ *         it -- NOT an fp32 matrix.  The weight gradients contract these bf16-rounded operands (fp32 accumulation).
  *   bits  [160, ld] uint16 sign words (relu' for the backward pass, 1 bit instead of 4 bytes per value): bit r of word
  *         bits[2 T + h][m] is set iff row 32 T + (r & 3) + 8 (r >> 2) + 4 h of `acts` is > 0 for sample m
  *   deltas a record like `acts`: every layer's pre-activation gradient, rows as in `acts`; rows 2432.. = d(raw) */
@@ -128,6 +135,7 @@ int ddnerf_dd_head(const float *raw6, int n, int nc, float smooth, float dist_re
  * outputs: rgb_map [n,3], disp [n], acc [n], weights [n,S], depth [n], cdisp [n], rgb [n,S,3] (may be NULL). */
 #define DDNERF_COMP_WHITE_BKGD 1
 #define DDNERF_COMP_BLENDER 2
+#define DDNERF_COMP_DP_FILTER 4  /* ddnerf_composite_forward_keep: keep[i] = sum(weights[i]) > 1e-10 (dataset type "blender"), else 1 */
 int ddnerf_composite_forward(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
                              const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc,
                              float *weights, float *depth, float *cdisp, float *rgb, ddnerf_stream_t stream);
@@ -168,6 +176,11 @@ int ddnerf_ray_bundle(int H, int W, float focal, const float *cam2world_host, fl
 /* ndc_mipnerf_rays  data_utils/dataset_helpers.py:3-42: NDC warp of a bundle + radii from neighbouring origins */
 int ddnerf_ndc_rays(int H, int W, float focal, float near_, const float *origins, const float *directions,
                     float *origins_ndc, float *directions_ndc, float *radii, ddnerf_stream_t stream);
+/* switch_t_ndc_to_regular  data_utils/dataset_helpers.py:45-49 (called at train_model.py:227-228): depth[i] =
+ * ndc_depth[i] * origins[i][2] / (directions[i][2] - ndc_depth[i] * directions[i][2]) + 1 over n = H*W pixels; origins / directions
+ * are the REGULAR (un-warped) bundle [H,W,3] of the same view. */
+int ddnerf_ndc_depth_to_regular(long n, const float *ndc_depth, const float *origins, const float *directions, float *depth,
+                                ddnerf_stream_t stream);
 
 /* ---- training: backward entry points --------------------------------------------------------------------
  * Gradient structure of the reference's graph: nothing flows through the samplers or the encoder;
@@ -192,6 +205,26 @@ size_t ddnerf_dd_records_workspace_bytes(int n, int nc);
 int ddnerf_dd_records(const float *weights, const float *mus, const float *sigmas, const float *ssig, int n, int nc,
                       float *out_mus, float *out_sigmas, float *out_ssig, int *total, void *workspace,
                       ddnerf_stream_t stream);
+/* The coarse pass of DDNerfModel behind the MLP on the render path (models/models.py:242-295) as TWO launches instead of five: (1) DD head +
+ * compositing with the head's mus + flags / counts of the level-0 records, wave per ray; (2) the records' ordered writes + the
+ * regularisers' final sums.  Arguments and outputs as for ddnerf_dd_head, ddnerf_composite_forward (flags; cdisp required) and
+ * ddnerf_dd_records (rec_*: capacity n * nc; rec_total [1]); bit for bit their outputs at nc = 64 (elsewhere the regulariser
+ * partial sums are grouped per 4 rays instead of per 256 elements).  workspace: ddnerf_dd_coarse_workspace_bytes(n, nc). */
+size_t ddnerf_dd_coarse_workspace_bytes(int n, int nc);
+int ddnerf_dd_coarse_forward(const float *raw6, const float *t_vals, const float *rays, const float *noise, int n, int nc, int flags,
+                             float smooth, float dist_reg, float *mus, float *sigmas, float *left, float *part, float *ssig,
+                             float *sleft, float *spart, float *scal, float *rgb_map, float *disp, float *acc, float *weights,
+                             float *depth, float *cdisp, float *rec_mus, float *rec_sigmas, float *rec_ssig, int *rec_total,
+                             void *workspace, ddnerf_stream_t stream);
+/* The fine pass: compositing + the dp loss's row filter (models/dd_utils.py:16: torch.sum(w1) > 1e-10 IS the compositing's
+ * weight sum) in one launch; dp_workspace = a ddnerf_dp_loss_workspace_bytes(n) buffer, then handed to
+ * ddnerf_dp_loss_forward_kept, which is ddnerf_dp_loss_forward without its first launch. */
+int ddnerf_composite_forward_keep(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
+                                  const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc, float *weights,
+                                  float *depth, float *cdisp, void *dp_workspace, ddnerf_stream_t stream);
+int ddnerf_dp_loss_forward_kept(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,
+                                const float *sig0, const float *left0, const float *part0, int n, int nc, int nf, float *loss,
+                                const float *reg_scal, float *loss_total, void *workspace, ddnerf_stream_t stream);
 
 /* backward of estimate_dp_loss w.r.t. (w0, mus0, sig0); g_loss[0] = upstream gradient of the scalar loss.
  * workspace as for the forward. */
@@ -233,10 +266,10 @@ int ddnerf_mlp_f32_wgrad(const float *deltas, int drow0, int n_out, const float 
 int ddnerf_mlp_x3_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,
                          long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
                          ddnerf_stream_t stream);
-/* The x3 training tier's own weight-gradient kernel: same contract, but `deltas` and `acts` are the RECORDS that
- * ddnerf_mlp_x3_forward_train and ddnerf_mlp_x3_backward_data write: 2560 rows x ld samples of "blocked hi/lo words".  Element
- * (row, sample m) is one 32-bit word (bf16 hi << 16) | bf16 lo, hi = bf16(x), lo = bf16(x - hi) (the split those kernels
- * compute for their own next layer anyway), at word index ((m >> 4) * 2560 + row) * 16 + (m & 15): 16-sample blocks, the
+/* The record-operand weight-gradient kernel of the fp32 tier: same contract, but `deltas` and `acts` are the RECORDS that
+ * ddnerf_mlp_f32_forward_train_rec and ddnerf_mlp_f32_backward_data_rec write: 2560 rows x ld samples of "blocked hi/lo words".  Element
+ * (row, sample m) is one 32-bit word (bf16 hi << 16) | bf16 lo, hi = bf16(x), lo = bf16(x - hi) (the value's exact split),
+ * at word index ((m >> 4) * 2560 + row) * 16 + (m & 15): 16-sample blocks, the
  * rows of a block back to back.  A job's rows of a block are one contiguous run that travels HBM -> LDS by LDS-DMA and feeds
  * the MFMAs without a split pass (4.7 TB/s where the [row][sample] fp32 operands of ddnerf_mlp_x3_wgrad reach 3.3).  ld must
  * be a multiple of 32.  max_workgroups (0 = 256) caps the split-K width: with 128, two jobs enqueued on two streams (each
@@ -247,6 +280,20 @@ int ddnerf_mlp_x3_wgrad(const float *deltas, int drow0, int n_out, const float *
 int ddnerf_mlp_x3_wgrad_packed(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
                                 long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
                                 int max_workgroups, ddnerf_stream_t stream);
+/* The x3 training tier's weight gradients: the same jobs on records of "bf16 row pairs" (what ddnerf_mlp_x3_forward_train and
+ * ddnerf_mlp_x3_backward_data write).  A record has ddnerf_mlp_act_rows() / 2 PAIR rows; the 32-bit word of (pair row p, sample m),
+ * at word index ((m >> 4) * 1280 + p) * 16 + (m & 15), holds bf16(row 2p) in its low and bf16(row 2p + 1) in its high half
+ * (round to nearest even) -- the packed conversion the training kernels make for their own next layer.  Half the bytes of the
+ * hi/lo-word records and ONE bf16 MFMA per product (fp32 accumulation): the usual mixed-precision weight gradient, relative error
+ * ~2^-9 per product, averaging down over the M samples of the contraction.  drow0 / arow0 / arow_a / arow_b are operand rows and
+ * must be even; everything else as for ddnerf_mlp_x3_wgrad_packed(_skip), pad columns included.  ddnerf_mlp_x3_split_pairs:
+ * fp32 [rows][ld] (rows, row0 even) -> rows row0 .. of such a record. */
+int ddnerf_mlp_x3_wgrad_pairs(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
+                              long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
+                              int max_workgroups, ddnerf_stream_t stream);
+int ddnerf_mlp_x3_wgrad_pairs_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
+                                   float *dst, float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream);
+int ddnerf_mlp_x3_split_pairs(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream);
 /* layers_xyz.5 (input cat(xyz, h4)) as ONE job over the same records: dst [256][352] = rows drow0.. of `deltas` against
  * cat(acts rows arow_a .. +96, acts rows arow_b .. +256); dst_bias [256]. */
 int ddnerf_mlp_x3_wgrad_packed_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,

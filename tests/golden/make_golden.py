@@ -632,7 +632,248 @@ def gen_raygen():
     save("raygen", **out)
 
 
+def gen_sampler4096():
+    """The sampler boundary at BASELINE size: the reference's own cfg2 coarse pass (4096 blender rays x 64 bins, validation, noise
+    off) feeds sample_pdf_with_mu_sigma; inputs exactly as the reference hands them over, the bin indices of all 4096 x 129
+    samples (uint8) and the samples."""
+    n, nc, nf = 4096, 64, 128
+    cfg = load_cfg(CFG_OF["blender"], nc, nf, "blender")
+    for mode in ("train", "validation"):
+        cfg.nerf[mode]["radiance_field_noise_std"] = 0.0
+    if cfg.train_params.set_automatic_dist_reg_coeficient:
+        cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+    model = ref_models.DDNerfModel(cfg)
+    load_weights(model.coarse, True, 11, 20.0)
+    load_weights(model.fine, False, 12, 20.0)
+    ro, rd, rad, tgt = synthetic.make_rays("blender", n, seed=1)
+    model.eval()
+    with Spy() as spy:
+        with torch.no_grad():
+            (_, ind) = capture_gather_index(model.run_iter, T(ro), T(rd), T(rad), mode="validation", rgb_target=T(tgt))
+    r = spy.rec
+    assert ind is not None and tuple(ind.shape) == (n, nf + 1) and int(ind.max()) < 256
+    assert bool((r["s_bins"] == r["s_bins"][0:1]).all())  # validation: one first-cycle row for every ray
+    save("sampler4096_cfg2", bins_row=r["s_bins"][0], weights=r["s_weights"], mus=r["s_mus"], ssig=r["s_ssig"], spart=r["s_spart"],
+         sleft=r["s_sleft"], bins_ind=ind.to(torch.uint8), samples=r["s_out"],
+         meta=np.array([n, nc, nf + 1, float(cfg.dataset.near), float(cfg.dataset.far), int(cfg.train_params.pdf_padding)], np.float64))
+
+
+def gen_grad4096():
+    """Parameter gradients at BASELINE size (cfg2: 4096 rays x (64 + 128), train mode with perturb / noise off so that no random
+    tensor is involved), every 61st entry of every parameter's gradient plus its norm and sum; with the dp term on and off."""
+    n, nc, nf = 4096, 64, 128
+    for tag, dp_on in (("dp1", True), ("dp0", False)):
+        cfg = load_cfg(CFG_OF["blender"], nc, nf, "blender")
+        for mode in ("train", "validation"):
+            cfg.nerf[mode]["radiance_field_noise_std"] = 0.0
+            cfg.nerf[mode]["perturb"] = False
+        if not dp_on:
+            cfg.train_params.dp_coeficient = 0.0
+        if cfg.train_params.set_automatic_dist_reg_coeficient:
+            cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+        model = ref_models.DDNerfModel(cfg)
+        load_weights(model.coarse, True, 11, 8.0)
+        load_weights(model.fine, False, 12, 8.0)
+        ro, rd, rad, tgt = synthetic.make_rays("blender", n, seed=6)
+        model.train()
+        out = model.run_iter(T(ro), T(rd), T(rad), mode="train", rgb_target=T(tgt))
+        mses = [torch.nn.functional.mse_loss(out[j]["rgb"], T(tgt)) for j in range(2)]
+        loss = sum(cfg.train_params.loss_coeficients[j] * mses[j] for j in range(2))
+        loss = loss + cfg.train_params.dp_coeficient * out[1]["dp_loss"].mean()
+        loss.backward()
+        rec = {"loss": loss.detach(), "mse": torch.stack([m.detach() for m in mses]), "dp_loss": out[1]["dp_loss"].detach()}
+        for pfx, net in (("c", model.coarse), ("f", model.fine)):
+            for name, p in net.named_parameters():
+                g = p.grad.reshape(-1)
+                rec["g%s_%s_sub" % (pfx, name)] = g[::61].clone()
+                rec["g%s_%s_stat" % (pfx, name)] = torch.stack([g.double().norm(), g.double().sum()])
+        save("grad4096_cfg2_" + tag, meta=np.array([n, nc, nf, 8.0, 0.0, float(cfg.dataset.near), float(cfg.dataset.far),
+                                                     float(cfg.train_params.dist_reg_coeficient), float(cfg.train_params.gaussian_smooth_factor),
+                                                     int(cfg.train_params.pdf_padding), float(cfg.train_params.dp_coeficient)]), **rec)
+        del out, loss, model
+
+
+def gen_train300():
+    """Training parity (SURVEY.md 8d "PSNR vs ref (2)"): 300 iterations of the reference's loop (train_model.py:132-177: smoothing
+    schedule, lr schedule, run_iter, loss assembly, backward, one Adam per network) on a procedural scene -- a fresh seeded batch of
+    256 rays per iteration with analytic colour targets -- with perturb / noise off (no random tensors).  The learning-rate
+    function is the reference's own (general_utils/nerf_helpers.py:211-245) with a 50-step warm-up instead of the 2500 the script
+    hard-wires (a 300-step run would otherwise never leave the warm-up).  Loss / MSE every 10 iterations."""
+    import functools
+
+    n, nc, nf, iters = 256, 64, 128, 300
+    for model_type, kind in (("DDNerfModel", "blender"), ("GeneralMipNerfModel", "blender")):
+        dd = model_type == "DDNerfModel"
+        cfg = load_cfg((CFG_OF if dd else CFG_MIP_OF)[kind], nc, nf, kind)
+        for mode in ("train", "validation"):
+            cfg.nerf[mode]["radiance_field_noise_std"] = 0.0
+            cfg.nerf[mode]["perturb"] = False
+        model = getattr(ref_models, cfg.nerf.type)(cfg)
+        load_weights(model.coarse, dd, 11, 1.0)
+        if dd:
+            load_weights(model.fine, False, 12, 1.0)
+        optims = [torch.optim.Adam(model.coarse.parameters(), lr=cfg.optimizer.lr)]
+        if dd:
+            optims.append(torch.optim.Adam(model.fine.parameters(), lr=cfg.optimizer.lr))
+        lr_function = functools.partial(ref_helpers.learning_rate_decay, lr_init=0.0005, lr_final=5e-6, max_steps=iters,
+                                        lr_delay_steps=50, lr_delay_mult=0.01)
+        dsmooth = (cfg.train_params.gaussian_smooth_factor - cfg.train_params.final_smooth) / cfg.train_params.finnish_smooth
+        initial_smooth = cfg.train_params.gaussian_smooth_factor
+        if cfg.train_params.set_automatic_dist_reg_coeficient:
+            cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+        rec = {"loss": [], "mse": [], "dp": [], "lr": [], "it": []}
+        for i in range(iters):
+            model.cfg.train_params.gaussian_smooth_factor = initial_smooth - dsmooth * i
+            model.train()
+            lr_new = lr_function(i)
+            for o in optims:
+                for g in o.param_groups:
+                    g["lr"] = lr_new
+            ro, rd, rad, _ = synthetic.make_rays(kind, n, seed=5000 + i)
+            tgt = synthetic.procedural_targets(ro, rd)
+            out = model.run_iter(T(ro), T(rd), T(rad), mode="train", rgb_target=T(tgt))
+            mses = [torch.nn.functional.mse_loss(out[j]["rgb"], T(tgt)) for j in range(len(out))]
+            loss = sum(cfg.train_params.loss_coeficients[j] * mses[j] for j in range(len(out)))
+            dp = torch.zeros(())
+            if dd:
+                dp = out[1]["dp_loss"].mean()
+                loss = loss + cfg.train_params.dp_coeficient * dp
+            loss.backward()
+            for o in optims:
+                o.step()
+                o.zero_grad()
+            if i % 10 == 0 or i == iters - 1:
+                rec["it"].append(i)
+                rec["loss"].append(float(loss))
+                rec["mse"].append([float(m) for m in mses])
+                rec["dp"].append(float(dp))
+                rec["lr"].append(float(lr_new))
+                print(model_type, i, float(loss), [float(m) for m in mses], flush=True)
+        save("train300_%s_%s" % ("dd" if dd else "mip", kind),
+             meta=np.array([n, nc, nf, iters, 50, float(cfg.dataset.near), float(cfg.dataset.far)]),
+             it=np.array(rec["it"]), loss=np.array(rec["loss"]), mse=np.array(rec["mse"]), dp=np.array(rec["dp"]), lr=np.array(rec["lr"]))
+
+
+def gen_ndcswitch():
+    """switch_t_ndc_to_regular (data_utils/dataset_helpers.py:45-49; called at train_model.py:227-228)"""
+    from data_utils.dataset_helpers import switch_t_ndc_to_regular
+
+    rng = np.random.Generator(np.random.PCG64(93))
+    H, W, focal = 7, 9, 13.0
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    pose = np.concatenate([q, rng.standard_normal((3, 1))], 1).astype(np.float32)
+    o, d, _ = ref_helpers.get_ray_bundle(H, W, focal, T(pose))
+    depth = T(rng.uniform(0.0, 0.98, (H, W)).astype(np.float32))
+    save("ndcswitch", ro=o, rd=d, ndc_depth=depth, regular=switch_t_ndc_to_regular(depth, o, d))
+
+
+def _placeholder_modules(*names):
+    """EMPTY modules under the names the reference's loader files import at their top (imageio, cv2, skimage.transform: absent
+    from this image) so that the import statements succeed.  They define nothing: only pure numpy functions of those files
+    are called below; whatever would touch an image library is replaced by synthetic arrays (see gen_loaders)."""
+    import types
+
+    for nm in names:
+        if nm not in sys.modules:
+            sys.modules[nm] = types.ModuleType(nm)
+            parent, _, child = nm.rpartition(".")
+            if parent:
+                setattr(sys.modules[parent], child, sys.modules[nm])
+
+
+def gen_colmap():
+    """COLMAP binary model readers (data_utils/poses/colmap_read_model.py:108-260, numpy + struct only) on a tiny synthetic model
+    that THIS build's writer (ddnerf_amd/colmap.py) produces; committed: the three .bin files and what the reference parsed.
+    Plus the poses / depth bounds the reference derives from the model (data_utils/poses/pose_utils.py:10-90, pure numpy behind
+    its imageio / skimage imports)."""
+    import importlib.util as iu
+    import json
+
+    spec = iu.spec_from_file_location("ddn_colmap", os.path.join(REPO, "ddnerf_amd", "colmap.py"))
+    colmap = iu.module_from_spec(spec)
+    spec.loader.exec_module(colmap)
+    from data_utils.poses import colmap_read_model as ref_cm
+
+    rng = np.random.Generator(np.random.PCG64(97))
+    root = os.path.join(HERE, "colmap_model")
+    sparse = os.path.join(root, "sparse", "0")
+    os.makedirs(sparse, exist_ok=True)
+    cams, imgs, pts = colmap.synthetic_model(rng, n_images=5, n_points=40)
+    colmap.write_cameras_binary(cams, os.path.join(sparse, "cameras.bin"))
+    colmap.write_images_binary(imgs, os.path.join(sparse, "images.bin"))
+    colmap.write_points3d_binary(pts, os.path.join(sparse, "points3D.bin"))
+    rc = ref_cm.read_cameras_binary(os.path.join(sparse, "cameras.bin"))
+    ri = ref_cm.read_images_binary(os.path.join(sparse, "images.bin"))
+    rp = ref_cm.read_points3d_binary(os.path.join(sparse, "points3D.bin"))
+    parsed = {
+        "cameras": {str(k): {"model": c.model, "width": int(c.width), "height": int(c.height), "params": [float(x) for x in c.params]}
+                    for k, c in rc.items()},
+        "images": {str(k): {"qvec": [float(x) for x in im.qvec], "tvec": [float(x) for x in im.tvec], "camera_id": int(im.camera_id),
+                            "name": im.name, "xys": np.asarray(im.xys).tolist(), "point3D_ids": [int(x) for x in im.point3D_ids],
+                            "rotmat": ref_cm.qvec2rotmat(im.qvec).tolist()} for k, im in ri.items()},
+        "points3D": {str(k): {"xyz": [float(x) for x in pt.xyz], "rgb": [int(x) for x in pt.rgb], "error": float(pt.error),
+                              "image_ids": [int(x) for x in pt.image_ids], "point2D_idxs": [int(x) for x in pt.point2D_idxs]}
+                     for k, pt in rp.items()},
+        "order": {"cameras": [int(k) for k in rc], "images": [int(k) for k in ri], "points3D": [int(k) for k in rp]},
+    }
+    _placeholder_modules("imageio", "skimage", "skimage.transform")
+    from data_utils.poses import pose_utils as ref_pu
+
+    poses, pts3d, perm = ref_pu.load_colmap_data(root)
+    out_dir = os.path.join("/tmp", "ddn_colmap_out")
+    os.makedirs(out_dir, exist_ok=True)
+    save_arr = ref_pu.save_poses(out_dir, poses, pts3d, perm)
+    parsed["poses"] = np.asarray(poses).tolist()
+    parsed["perm"] = [int(x) for x in perm]
+    parsed["poses_bounds"] = np.asarray(save_arr).tolist()
+    json.dump(parsed, open(os.path.join(root, "reference_parse.json"), "w"))
+    print("%-40s %8.1f KB" % ("colmap_model/", sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(root) for f in fs) / 1024))
+
+
+def gen_loaders():
+    """The pose pipelines of the scene loaders (data_utils/load_llff.py:138-368, data_utils/load_blender.py:9-65): pure numpy behind
+    imports of imageio / cv2, which this image lacks.  The import statements are satisfied by EMPTY placeholder modules; the one
+    function that reads image files (`_load_data`) is replaced by synthetic arrays for the call, so only the reference's own
+    numpy code runs: axis re-ordering, bd_factor rescale, recentring, spherify, spiral / circle render paths, hold-out view."""
+    _placeholder_modules("imageio", "cv2", "skimage", "skimage.transform")
+    from data_utils import load_llff as ref_llff
+    from data_utils import load_blender as ref_blender
+
+    rng = np.random.Generator(np.random.PCG64(99))
+    out = {}
+    N, H, W = 11, 6, 8
+    for tag, cfgname, kind, spherify, bd_factor in (("llff", "config_ff.yml", "llff", False, 0.75), ("real360", "config_360.yml", "real360", False, False),
+                                                    ("real360_sph", "config_360.yml", "real360", True, 0.75)):
+        cfg = load_cfg(cfgname, 8, 8)
+        cfg.dataset.spherify = spherify
+        cfg.dataset.bd_factor = bd_factor
+        cfg.dataset.basedir = "/nowhere/scene_" + tag
+        # LLFF raw convention: [3,5,N] with rotation columns [down, right, back], translation, (H, W, focal)
+        ang = rng.uniform(-0.4, 0.4, (N, 3)) if kind == "llff" else rng.uniform(-3.1, 3.1, (N, 3))
+        poses = np.zeros((3, 5, N))
+        for i in range(N):
+            q, _ = np.linalg.qr(np.eye(3) + 0.5 * rng.standard_normal((3, 3)) * (0.3 if kind == "llff" else 2.0))
+            if np.linalg.det(q) < 0:
+                q[:, 0] = -q[:, 0]
+            poses[:, :3, i] = q
+            poses[:, 3, i] = rng.standard_normal(3) * (0.5 if kind == "llff" else 2.0)
+            poses[:, 4, i] = (H, W, 9.5)
+        bds = np.sort(rng.uniform(0.8, 9.0, (2, N)), 0)
+        imgs = rng.random((H, W, 3, N))
+        ref_llff._load_data = lambda basedir, factor=None, _p=poses, _b=bds, _i=imgs: (_p.copy(), _b.copy(), _i.copy())
+        images, p_out, b_out, render_poses, i_test = ref_llff.load_data_after_colmap(cfg)
+        out.update({tag + "_in_poses": poses, tag + "_in_bds": bds, tag + "_in_imgs": imgs.astype(np.float32), tag + "_images": images, tag + "_poses": p_out,
+                    tag + "_bds": b_out, tag + "_render": np.asarray(render_poses), tag + "_itest": np.array(int(i_test)),
+                    tag + "_flags": np.array([int(spherify), float(bd_factor) if bd_factor else 0.0])})
+    # free-standing pose helpers
+    out["pose_spherical"] = np.stack([npy(ref_blender.pose_spherical(a, -30.0, 4.0)) for a in np.linspace(-180, 180, 7)[:-1]])
+    out["pose_360_beta"] = np.stack([np.asarray(ref_blender.pose_spherical_for_real_world_360(a, -10, 0.89, "beta")) for a in (0.0, 45.0, 200.0)])
+    out["pose_360_other"] = np.stack([np.asarray(ref_blender.pose_spherical_for_real_world_360(a, -10, 0.89, "garden")) for a in (0.0, 45.0, 200.0)])
+    save("loaders", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps", "fullsize", "manifest", "depthanalysis"]
+    which = sys.argv[1:] or ["first_cycle", "encode", "composite", "samplers", "runiter", "dploss", "aten_orders", "raygen", "trainsteps", "fullsize", "manifest", "depthanalysis", "sampler4096", "grad4096", "train300", "ndcswitch",
+                             "colmap", "loaders"]
     for w in which:
         globals()["gen_" + w]()

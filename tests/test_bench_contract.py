@@ -35,10 +35,18 @@ def test_render_line_has_the_contract_fields():
     assert r["traffic"] is None or r["traffic"] > 2.7e8        # at least the algorithmic bytes
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    for tier, lo in (("x3_tier", 0.2), ("bf16_tier", 0.2)):
+    for tier, lo in (("x3_tier", 0.1), ("bf16_tier", 0.2)):   # `frac` counts algorithmic FLOP: the x3 kernel issues 3x that
         t = d[tier]
         assert t["value"] > d["value"] and t["roofline"]["peak"] == 2500.0 and lo < t["roofline"]["frac"] < 1.0, tier
-    assert d["train_tier"]["x3"]["value"] > d["train_tier"]["fp32"]["value"] > 0
+    x3 = d["x3_tier"]["roofline"]
+    assert abs(x3["frac_issued"] - 3 * x3["frac"]) < 2e-3 and 0.3 < x3["frac_issued"] < 1.0
+    # the bf16 line carries what its fraction is made of: the in-kernel clock and the matrix-pipe busy share (diagnostic build)
+    clk = d["bf16_tier"]["roofline"]["clock"]
+    assert 1000 < clk["in_kernel_clock_mhz"] <= 2500 and 0.5 < clk["mfma_busy"] <= 1.0
+    assert abs(clk["mfma_busy"] - clk["ideal_cycles_per_tile"] / clk["cycles_per_256_sample_tile"]) < 1e-3
+    tt = d["train_tier"]
+    assert tt["x3"]["value"] > tt["fp32"]["value"] > 0
+    assert abs(tt["x3"]["roofline"]["frac_issued"] - 3 * tt["x3"]["roofline"]["frac"]) < 2e-3
 
 
 def test_train_line():

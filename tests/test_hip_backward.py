@@ -160,10 +160,11 @@ def test_mlp_backward_vs_autograd(ops, depth, M, mlp_dtype):
         ref = sdr[name].grad
         if mlp_dtype == "fp32":
             close(p.grad, ref, 1e-3, 2e-5 * float(ref.abs().max()))
-        else:  # products carry a relative error of ~2^-16: a wrong tile, row map or sign bit would be off by O(1)
+        else:  # the x3 tier's weight gradients contract bf16-rounded activations and deltas (one MFMA per product, fp32 accumulation):
+            # relative error ~2^-9 per product, measured 2.2e-3 of the norm; a wrong tile, row map or sign bit would be off by O(1)
             a, b = p.grad.double(), ref.double()
-            assert float((a - b).norm()) <= 3e-4 * float(b.norm()) + 1e-12, (name, float((a - b).norm() / b.norm()))
-            assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()), name
+            assert float((a - b).norm()) <= 4e-3 * float(b.norm()) + 1e-12, (name, float((a - b).norm() / b.norm()))
+            assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), name
     # the parameter gradients are views of ONE flat buffer (the data-parallel bucket)
     flat = net.last_flat_grad
     assert next(net.parameters()).grad.data_ptr() == flat.data_ptr()
@@ -313,6 +314,8 @@ def test_weight_gradient_kernels_at_full_size(ops):
     # the x3 tier's own kernel reads records of blocked hi/lo words (what its forward / backward kernels write)
     rec_a, rec_d = ops.x3_split(acts), ops.x3_split(deltas)
     assert float((ops.x3_unsplit(rec_a) - acts).abs().max()) <= 2.0 ** -16 * float(acts.abs().max())
+    pair_a, pair_d = ops.x3_split_pairs(acts), ops.x3_split_pairs(deltas)
+    assert torch.equal(ops.x3_unpair(pair_a)[::97], acts[::97].bfloat16().float())
     for drow0, n_out, arow0, n_in, used, col0, ld in ((512, 256, 256, 256, 256, 0, 256), (0, 256, 2432, 96, 96, 0, 96),
                                                       (1280, 256, 1024, 256, 256, 96, 352), (2432, 3, 2304, 128, 128, 0, 128)):
         outs = {}
@@ -332,6 +335,18 @@ def test_weight_gradient_kernels_at_full_size(ops):
                 assert float(w[:, :col0].abs().max()) == 0.0          # columns outside the job are not touched
         assert float((outs["x3"][0] - outs["f32"][0]).abs().max()) <= 5e-5 * scale
         assert torch.equal(outs["x3"][0], outs["x3p"][0])   # same splits, same partition, same MFMA order: bit-identical
+        # the x3 training tier's kernel: records of bf16 row pairs, one MFMA per product -- exact on the bf16-rounded operands,
+        # and the usual mixed-precision distance (2^-9 per product, random signs) from the fp32 ones
+        w = torch.zeros(n_out, ld, device="cuda")
+        b = torch.zeros(n_out, device="cuda")
+        ops.mlp_f32_wgrad_job(pair_d, drow0, n_out, pair_a, arow0, n_in, used, M, w, ld, col0, b, ws, mode="x3h")
+        dq, aq = deltas[drow0:drow0 + n_out].bfloat16().float(), acts[arow0:arow0 + used].bfloat16().float()
+        ref_q = dq @ aq.T
+        assert float((w[:, col0:col0 + used] - ref_q).abs().max()) <= 2e-4 * float(ref_q.abs().max()), ("x3h", drow0)
+        assert float((w[:, col0:col0 + used] - ref_w).norm()) <= 4e-3 * float(ref_w.norm()), ("x3h vs fp32", drow0)
+        assert float((b - dq.double().sum(1).float()).abs().max()) <= 1e-4 * float(ref_b.abs().max()) + 1e-7
+        if col0:
+            assert float(w[:, :col0].abs().max()) == 0.0
     # layers_xyz.5 as one job over cat(xyz rows, h4 rows) == its two single-range jobs
     w2 = torch.zeros(256, 352, device="cuda")
     b2 = torch.zeros(256, device="cuda")
@@ -344,6 +359,13 @@ def test_weight_gradient_kernels_at_full_size(ops):
                                                                   torch.cuda.current_stream().cuda_stream), "skip")
     assert torch.equal(w1, w2)
     assert float((b1 - b2).abs().max()) <= 1e-6 * float(b2.abs().max())
+    w3 = torch.zeros(256, 352, device="cuda")
+    b3 = torch.zeros(256, device="cuda")
+    ops._lib.check(ops._lib.lib().ddnerf_mlp_x3_wgrad_pairs_skip(pair_d.data_ptr(), 1280, pair_a.data_ptr(), 2432, 1024, M, pair_d.shape[1],
+                                                                 w3.data_ptr(), b3.data_ptr(), ws.data_ptr(), 0,
+                                                                 torch.cuda.current_stream().cuda_stream), "pairs_skip")
+    ref3 = deltas[1280:1536].bfloat16().float() @ torch.cat([acts[2432:2528], acts[1024:1280]]).bfloat16().float().T
+    assert float((w3 - ref3).abs().max()) <= 2e-4 * float(ref3.abs().max())
 
 
 def test_training_kernels_at_full_size(ops):
@@ -362,11 +384,12 @@ def test_training_kernels_at_full_size(ops):
     raw_x, acts_x, bits = ops.mlp_x3_forward_train(feat, ops.mlp_x3_pack(flat, depth), depth)
     assert float((raw_f - raw_x).abs().max()) <= 2e-5 * float(raw_f.abs().max())
     rows = torch.cat([torch.arange(0, 2432, 37, device="cuda"), torch.arange(2432, 2555, device="cuda")])
-    acts_xv = ops.x3_unsplit(acts_x)     # (the x3 kernels record blocked hi/lo words)
+    acts_xv = ops.x3_unpair(acts_x)     # (the x3 kernels record bf16 row pairs: the bf16 rounding of the values they compute)
     a, b = acts_f[rows], acts_xv[rows]
-    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
-    # the transposed input columns: the exact hi/lo split of the features
-    assert torch.equal(ops.x3_split(acts_f).view(torch.int32).view(-1, 2560, 16)[:, 2432:2555], acts_x.view(torch.int32).view(-1, 2560, 16)[:, 2432:2555])
+    assert float((a - b).abs().max()) <= 2.0 ** -8 * float(a.abs().max())
+    assert float((a - b).norm()) <= 2.0 ** -9 * float(a.norm())
+    # the transposed input columns: exactly the bf16 rounding of the features
+    assert torch.equal(ops.x3_split_pairs(acts_f).view(torch.int32).view(-1, 1280, 16)[:, 1216:1280], acts_x.view(torch.int32).view(-1, 1280, 16)[:, 1216:1280])
     d_f = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_f, depth)
     d_x = ops.mlp_x3_backward_data(G, ops.mlp_x3_pack_t(flat, depth), bits, depth)
     # the exact-fp32 kernels' record-writing build (what the fp32 tier runs with the default weight gradients): the same
@@ -378,7 +401,7 @@ def test_training_kernels_at_full_size(ops):
     assert torch.equal(d_r.view(torch.int32).reshape(-1, 2560, 16)[:, :2438], ops.x3_split(d_f).view(torch.int32).reshape(-1, 2560, 16)[:, :2438])
     del raw_r, acts_r, d_r
     rows = torch.cat([torch.arange(0, 2432, 41, device="cuda"), torch.arange(2432, 2438, device="cuda")])
-    a, b = d_f[rows], ops.x3_unsplit(d_x)[rows]
-    off = (a - b).abs() > 1e-4 * float(a.abs().max())
+    a, b = d_f[rows], ops.x3_unpair(d_x)[rows]                                      # (bf16 roundings of the x3 chain's deltas)
+    off = (a - b).abs() > 2.0 ** -7 * a.abs() + 1e-4 * float(a.abs().max())
     assert float(off.float().mean()) <= 1e-4, float(off.float().mean())            # kink flips only (measured ~1e-5)
-    assert float((a - b).norm()) <= 2e-3 * float(a.norm())
+    assert float((a - b).norm()) <= 3e-3 * float(a.norm())

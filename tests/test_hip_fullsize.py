@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from _cases import fullsize_names, load_fullsize, relerr
+from _cases import fullsize_names, load_fullsize, maxerr, relerr
 from ddnerf_amd import synthetic
 
 pytestmark = pytest.mark.gpu
@@ -35,7 +35,9 @@ def test_full_size_matches_reference(name, mlp_dtype):
     assert len(out) == 2
     for lvl in (0, 1):
         for k in ("rgb", "depth", "acc", "disp", "weights"):
-            e = relerr(out[lvl][k][::st].cpu().numpy(), g["o%d_%s" % (lvl, k)])
+            # north_star: RGB / depth within 1e-4 -- ABSOLUTE (depth reaches far = 6); only the disparity, which reaches 1e10 on
+            # empty rays, is held relatively
+            e = (relerr if k == "disp" else maxerr)(out[lvl][k][::st].cpu().numpy(), g["o%d_%s" % (lvl, k)])
             assert e <= 1e-4, (name, lvl, k, e)
     if c["dd"]:
         ref = float(g["o1_dp_loss"][0])

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from _cases import load_runiter, relerr, runiter_names
+from _cases import load_runiter, maxerr, relerr, runiter_names
 from ddnerf_amd.cfgnode import CfgNode
 
 pytestmark = pytest.mark.gpu
@@ -88,7 +88,8 @@ def test_run_iter_forward_matches_reference(name):
     assert len(out) == 2
     for lvl in (0, 1):
         for k in ("rgb", "depth", "disp", "acc", "weights"):
-            e = relerr(out[lvl][k].cpu().numpy(), g["o%d_%s" % (lvl, k)])
+            # ABSOLUTE error for everything but the disparity (1e10 on empty rays): depth reaches far = 6
+            e = (relerr if k == "disp" else maxerr)(out[lvl][k].cpu().numpy(), g["o%d_%s" % (lvl, k)])
             assert e <= 1e-4, (lvl, k, e)          # north_star bar
             if lvl == 0:
                 assert e <= 5e-6, (lvl, k, e)      # the coarse pass has no sampler in front of it: near-ulp
@@ -125,7 +126,7 @@ def test_run_iter_x3_meets_the_fp32_bar(name):
         out = model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode=c["mode"], rgb_target=d(g["tgt"]))
     for lvl in (0, 1):
         for k in ("rgb", "depth", "disp", "acc", "weights"):
-            e = relerr(out[lvl][k].cpu().numpy(), g["o%d_%s" % (lvl, k)])
+            e = (relerr if k == "disp" else maxerr)(out[lvl][k].cpu().numpy(), g["o%d_%s" % (lvl, k)])
             assert e <= 1e-4, (lvl, k, e)
 
 

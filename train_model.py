@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from ddnerf_amd import data, schedules  # noqa: E402
+from ddnerf_amd import data, ops, schedules  # noqa: E402
 from ddnerf_amd.cfgnode import CfgNode  # noqa: E402
 from ddnerf_amd.train_step import TrainStepper  # noqa: E402
 from models import models  # noqa: E402
@@ -92,8 +92,12 @@ def main():
                 vo, vd, vr, img = val_dataset.get_next_validation_rays(device)
                 out = model.run_iter(vo, vd, vr, mode="validation", rgb_target=img)
                 mses = [float(torch.nn.functional.mse_loss(out[j]["rgb"], img)) for j in range(2)]
+                if cfg.dataset.ndc_rays:  # train_model.py:226-228: NDC depth maps back in camera-space units (device op)
+                    ro_reg, rd_reg, _ = val_dataset.get_current_regular_validation_rays(device)
+                    for j in range(2):
+                        out[j]["depth"] = ops.ndc_depth_to_regular(out[j]["depth"], ro_reg, rd_reg)
             rec = {"iter": i, "val_psnr_coarse": schedules.mse2psnr(mses[0]), "val_psnr_fine": schedules.mse2psnr(mses[1]),
-                   "val_time_s": time.time() - t0}
+                   "val_depth_fine_mean": float(out[1]["depth"].mean()), "val_time_s": time.time() - t0}
             print("[VAL] =======> Iter: %d Validation PSNR: %s Time: %s" % (i, rec["val_psnr_fine"], rec["val_time_s"]))
             log.write(json.dumps(rec) + "\n")
             log.flush()
