@@ -37,7 +37,8 @@ FLOP_COARSE_DD = 1221120  # per sample, DepthMipNeRFModel forward
 PEAK = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 DTYPE = {"fp32": "f32", "bf16": "bf16 (f32 accumulate)", "x3": "f32 as exact hi+lo bf16 splits, 3 bf16 MFMAs per product (f32 accumulate)"}
 TRAIN_DTYPE = {"fp32": "f32 forward / backward-data, weight gradients as bf16 hi+lo splits (3 MFMAs per product, f32 accumulate)",
-               "x3": DTYPE["x3"]}
+               "x3": "f32 forward / backward-data as exact hi+lo bf16 splits (3 bf16 MFMAs per product), weight gradients from bf16-rounded "
+                     "activation / delta records (1 MFMA per product); f32 accumulation throughout"}
 # BASELINE.json configs -> (synthetic ray kind, default MLP kernel, default rays per GPU)
 CONFIGS = {
     "config_blender.yml": ("blender", "fp32", 4096),          # configs[1] (and [0] at 256 rays)
@@ -517,7 +518,7 @@ def train_roofline(args, cfg, step_s):
     # algorithmic: every product once, on the unit it runs on; issued: the hi/lo-split passes issue three bf16 MFMAs per product
     if args.mlp == "x3":
         ideal = (fwd + bwd + wgrad) / (PEAK["x3"] * 1e12)
-        issued = 3 * ideal
+        issued = (3 * (fwd + bwd) + wgrad) / (PEAK["x3"] * 1e12)
     else:
         ideal = (fwd + bwd) / (PEAK["fp32"] * 1e12) + wgrad / (PEAK["x3"] * 1e12)
         issued = (fwd + bwd) / (PEAK["fp32"] * 1e12) + 3 * wgrad / (PEAK["x3"] * 1e12)
@@ -526,7 +527,7 @@ def train_roofline(args, cfg, step_s):
             "frac": round(ideal / step_s, 4), "frac_issued": round(issued / step_s, 4), "issued_ideal_ms": round(issued * 1e3, 4),
             "unit": "fraction of the step time the (algorithmic / issued) FLOP need at the dense MFMA peaks",
             "peaks_tflops": {"fp32_mfma": PEAK["fp32"], "bf16_mfma": PEAK["x3"]},
-            "note": ("forward / backward-data / weight gradients all as three bf16 MFMAs per product" if args.mlp == "x3" else
+            "note": ("forward / backward-data as three bf16 MFMAs per product, weight gradients as one (bf16-rounded records)" if args.mlp == "x3" else
                      "forward / backward-data on the fp32 matrix cores, weight gradients as three bf16 MFMAs per product")}
 
 

@@ -60,7 +60,8 @@ def _compile_checked(cmd, src, obj, kernel, verbose):
         if bad:
             raise RuntimeError("%s: %d dependent instruction pairs closer than the unpadded wait states, e.g.\n%s" % (src, len(bad), bad[0]))
         if verbose:
-            print("%s: %d MFMAs, no too-close dependent pair" % (src, n), flush=True)
+            print("%s: %d MFMAs, no too-close dependent pair (straight-line scan + %d loop back-edge seams: not a proof, the bit-exact "
+                  "GPU tests are the gate)" % (src, n, check_asm_hazards.check.seams), flush=True)
         shutil.move(os.path.join(tmp, base), obj)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

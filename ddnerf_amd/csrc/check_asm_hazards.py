@@ -32,8 +32,9 @@ def regs(tok):
     return out
 
 
-def parse(path, kernel):
-    ins, on = [], False
+def parse(path, kernel, with_labels=False):
+    """instructions of every instantiation of `kernel`; with_labels: also (label -> index of the instruction behind it)"""
+    ins, on, labels = [], False, {}
     for line in open(path):
         if re.match(r"^_Z\w*%s\w*:" % kernel, line):
             on = True
@@ -44,12 +45,16 @@ def parse(path, kernel):
         if s.startswith("s_endpgm"):
             on = False
             continue
+        lab = s.split(";")[0].strip()       # (".LBB0_6:      ; =>This Inner Loop Header")
+        if lab.endswith(":") and lab.startswith(".L"):
+            labels[lab[:-1]] = len(ins)
+            continue
         if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
             continue
         mnem, _, rest = s.partition(" ")
         ops = [o.strip() for o in rest.split(";")[0].split(",")] if rest else []
         ins.append((mnem, ops, s))
-    return ins
+    return (ins, labels) if with_labels else ins
 
 
 def defs_uses(mnem, ops):
@@ -63,10 +68,38 @@ def defs_uses(mnem, ops):
     return set(), set().union(*[regs(o) for o in ops]) if ops else set()
 
 
+WINDOW = 48  # instructions on either side of a loop's back edge that are scanned as one straight line
+
+
 def check(path, kernel="mlp_bf16_fwd_kernel"):
-    ins = parse(path, kernel)
+    """Limits (the bit-exact GPU tests remain the real gate): the scan is a straight line over the listing plus, for every BACKWARD
+    branch, the last WINDOW instructions in front of it followed by the first WINDOW behind its target (the tile loop's wrap-around);
+    forward branches are not followed; operand 0 of an instruction is taken as its only definition (instructions that also
+    write an SGPR / VCC are not modelled: none of them feeds an MFMA here); the distances are empirical (see above)."""
+    ins, labels = parse(path, kernel, with_labels=True)
     if not any(m.startswith("v_mfma") for m, _, _ in ins):
         raise SystemExit("check_asm_hazards: no MFMA found in %s (kernel %s)" % (path, kernel))
+    n, bad = _scan(ins)
+    far = None  # target of a long branch being assembled: s_getpc_b64 / s_add_u32 x, x, (.LBBn_m-.Lpost_getpck)&... / s_setpc_b64
+    seams = 0
+    for p, (m, o, text) in enumerate(ins):  # loop back edges: scan the seam
+        q = None
+        if m.startswith("s_cbranch") or m == "s_branch":
+            q = labels.get(o[0]) if o else None
+        elif m == "s_add_u32":
+            t = re.search(r"\((\.LBB\w+)-\.Lpost_getpc\d+\)&", text)
+            far = t.group(1) if t else far
+        elif m == "s_setpc_b64":
+            q, far = labels.get(far), None
+        if q is not None and q <= p:
+            seams += 1
+            seam = ins[max(q, p - WINDOW):p] + ins[q:q + WINDOW]
+            bad += [b for b in _scan(seam)[1] if b not in bad]
+    check.seams = seams
+    return n, bad
+
+
+def _scan(ins):
     du = [defs_uses(m, o) for m, o, _ in ins]
     # wait states an instruction contributes to a distance: s_nop n -> n + 1; an MFMA holds the issue port for 8 cycles -> 2
     slots = [int(o[0]) + 1 if m == "s_nop" and o else (2 if m.startswith("v_mfma") else 1) for m, o, _ in ins]
@@ -102,5 +135,6 @@ if __name__ == "__main__":
     n, bad = check(sys.argv[1], *(sys.argv[2:3]))
     for b in bad[:20]:
         print(b)
-    print("check_asm_hazards: %d MFMAs, %d too-close dependent pairs" % (n, len(bad)))
+    print("check_asm_hazards: %d MFMAs, %d too-close dependent pairs (straight-line scan + %d loop back-edge seams; limits: check.__doc__)"
+          % (n, len(bad), check.seams))
     sys.exit(1 if bad else 0)

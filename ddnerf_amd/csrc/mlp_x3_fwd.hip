@@ -9,8 +9,8 @@
 // rows are the fp32 [M,128] matrix in natural column order; they are split into planes while they move to the accumulator
 // half.  The re-pack of a finished tile is ten small steps (ReLU, hi, hi as float, x - hi, lo, home hi, home lo) dealt over
 // the MFMA gaps of the next block.
-// Replaces the 32x32x16 forward of round 1; mlp_x3_fwd_train.hip is this kernel plus the training records (mlp_x3_train.hip, the
-// backward-data pass, keeps the 32x32x16 formulation).
+// Replaces the 32x32x16 forward of round 1; mlp_x3_fwd_train.hip is this kernel plus the training records, mlp_x3_bwd.hip the
+// backward-data pass on the same body (transposed steps).
 #include "common.h"
 #define M16_PLANES 2
 #define M16_SYM(x) ddnerf_mlp_x3_##x

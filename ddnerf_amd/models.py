@@ -33,6 +33,17 @@ class TorchRng:
         """randn * std in ONE kernel (the generator applies the scale: same values as the two-step form)"""
         return torch.empty(shape, dtype=torch.float32, device=device).normal_(0.0, float(std))
 
+    def randn_scaled_pair(self, n, s0, s1, device, std):
+        """the compositing noise of BOTH levels of a chunk from ONE generator launch: [n, s0] and [n, s1] (independent normals;
+        only the order in which the generator's stream is consumed differs from two calls)"""
+        both = torch.empty(n * (s0 + s1), dtype=torch.float32, device=device).normal_(0.0, float(std))
+        return both[:n * s0].view(n, s0), both[n * s0:].view(n, s1)
+
+
+# render-path launch folding (see DDNerfModel.predict); DDNERF_FUSE_RENDER=0 keeps the one-kernel-per-reference-function path
+import os as _os
+
+FUSE_RENDER = _os.environ.get("DDNERF_FUSE_RENDER", "1") != "0"
 
 _const_cache = {}
 
@@ -123,6 +134,17 @@ class GeneralMipNerfModel(torch.nn.Module):
 
     def get_rays_batches(self, ray_origins, ray_directions, ray_rad, mode):
         """models/models.py:144-162 (K0 pack kernel, then views of <= chunksize rays)"""
+        self._t0_ready = None
+        mc = self._mode_cfg(mode)
+        n = ray_directions.numel() // 3
+        if (FUSE_RENDER and n <= mc.chunksize and not mc.perturb and not self.cfg.dataset.get("combined_sampling_method", False)):
+            # ONE chunk and no jitter draw: the packed rows and the first-cycle fenceposts come out of one launch (the same
+            # arithmetic as the two kernels); predict picks the fenceposts up instead of launching sample_first_cycle
+            t_lin = _host_const("linspace", 0.0, 1.0, mc.num_coarse + 1, ray_directions.device)
+            rays, t0 = ops.pack_rays_first_cycle(ray_origins, ray_directions, ray_rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin,
+                                                 None, bool(mc.lindisp))
+            self._t0_ready = (rays.data_ptr(), t0)
+            return [rays]
         rays = ops.pack_rays(ray_origins, ray_directions, ray_rad, self.cfg.dataset.near, self.cfg.dataset.far)
         return get_minibatches(rays, chunksize=getattr(self.cfg.nerf, mode).chunksize)
 
@@ -155,11 +177,22 @@ class GeneralMipNerfModel(torch.nn.Module):
         """models/samplers.py:30-62"""
         mc = self._mode_cfg(mode)
         nc = mc.num_coarse
+        ready = getattr(self, "_t0_ready", None)
+        if ready is not None and ready[0] == rays.data_ptr() and ready[1].shape == (rays.shape[0], nc + 1):
+            self._t0_ready = None
+            return ready[1]          # (get_rays_batches computed them with the packed rows)
         t_rand = self.rng.rand((rays.shape[0], nc + 1), rays.device) if mc.perturb else None
         if self.cfg.dataset.get("combined_sampling_method", False):   # models/samplers.py:45-49
-            row = _combined_row(float(self.cfg.dataset.near), float(self.cfg.dataset.combined_split), float(self.cfg.dataset.far), nc,
-                                rays.device)
-            return ops.sample_first_cycle(rays, row, t_rand, 2)
+            # `far[0]` of the reference is the packed rows' far column, i.e. cfg.dataset.far.  Like the reference (a bare try / except
+            # around this branch, :44-51) anything that goes wrong here -- no dataset.combined_split, an odd num_coarse -- silently
+            # leaves the linear fenceposts in place.
+            try:
+                row = _combined_row(float(self.cfg.dataset.near), float(self.cfg.dataset.combined_split), float(self.cfg.dataset.far), nc,
+                                    rays.device)
+            except Exception:
+                row = None
+            if row is not None:
+                return ops.sample_first_cycle(rays, row, t_rand, 2)
         t_lin = _host_const("linspace", 0.0, 1.0, nc + 1, rays.device)
         return ops.sample_first_cycle(rays, t_lin, t_rand, bool(mc.lindisp))
 
@@ -233,6 +266,12 @@ class DDNerfModel(GeneralMipNerfModel):
         blender = self._is_blender()
         ret = {}
         model = self.coarse
+        # one generator launch for the compositing noise of both levels where the random source offers it (TorchRng does; a replaying
+        # source in the parity tests does not and is asked level by level, in the reference's draw order)
+        pair = getattr(self.rng, "randn_scaled_pair", None)
+        noise_pair = None
+        if FUSE_RENDER and pair is not None and mc.radiance_field_noise_std > 0.0:
+            noise_pair = pair(n, mc.num_coarse, mc.num_fine, dev, mc.radiance_field_noise_std)
         for i in range(2):
             if i == 1:
                 model = self.fine
@@ -252,14 +291,30 @@ class DDNerfModel(GeneralMipNerfModel):
                                                  head["spart"].detach(), head["sleft"].detach(), u_base, rnd,
                                                  cfg.dataset.near, cfg.dataset.far, bool(cfg.train_params.pdf_padding))
             raw = self.run_network(ray_batch, t_vals, model, mode)
-            if i == 0:
+            if noise_pair is not None:
+                noise = noise_pair[i]
+            else:
+                noise = self._noise(n, t_vals.shape[1] - 1, mode, dev)
+            # Render path (nothing to differentiate): the small kernels behind each MLP are folded -- coarse: DD head + compositing +
+            # record flags in one launch, the records' writes + the regularisers' sums in a second (five before); fine: compositing +
+            # the dp loss's row filter in one.  Same arithmetic, same outputs (ops.dd_coarse_forward / composite_forward_keep).
+            fused = FUSE_RENDER and not (torch.is_grad_enabled() and raw.requires_grad)
+            dp_ws = None
+            if i == 0 and fused:
+                c, head, records = ops.dd_coarse_forward(raw, t_vals, ray_batch, noise, cfg.train_params.gaussian_smooth_factor,
+                                                         cfg.train_params.dist_reg_coeficient, bool(mc.white_background), blender)
+            elif i == 0:
                 head = F.dd_head(raw, cfg.train_params.gaussian_smooth_factor, cfg.train_params.dist_reg_coeficient)
+            if i == 0:
                 mus, sigmas = head["mus"], head["sigmas"]
                 smoothed_sigmas = head["ssig"]
                 scal = head["scal"]
                 mus_loss, sig_loss, mus_reg, sig_reg = scal[0], scal[1], scal[2], scal[3]
-            c = F.composite(raw, t_vals, ray_batch, self._noise(n, t_vals.shape[1] - 1, mode, dev), mus,
-                            bool(mc.white_background), blender)
+            dp_blender = str(cfg.dataset.type).lower() == "blender"
+            if i == 1 and fused:
+                c, dp_ws = ops.composite_forward_keep(raw, t_vals, ray_batch, noise, mus, bool(mc.white_background), blender, dp_blender)
+            elif not (i == 0 and fused):
+                c = F.composite(raw, t_vals, ray_batch, noise, mus, bool(mc.white_background), blender)
             weights = c["weights"]
             if i == 0:
                 t_vals_0, mus_0, sigmas_0, weights_0 = t_vals, mus, sigmas, weights
@@ -267,15 +322,18 @@ class DDNerfModel(GeneralMipNerfModel):
                 # indexing has a data-dependent size, i.e. a host sync.  ONE stream compaction serves the three records; it
                 # is enqueued here, as soon as its inputs exist, with an asynchronous copy of the length: when the host
                 # asks for it (end of the chunk) the GPU is still busy with the fine pass, so it never runs dry.
-                with torch.no_grad():
-                    records = ops.dd_records_launch(weights_0, mus_0, sigmas_0, smoothed_sigmas)
+                if not fused:
+                    with torch.no_grad():
+                        records = ops.dd_records_launch(weights_0, mus_0, sigmas_0, smoothed_sigmas)
             dp_loss = None
             if i == 1:
                 dp_args = (t_vals.detach(), t_vals_0.detach(), weights.detach(), weights_0, mus_0, sigmas_0,
-                           head["left"].detach(), head["part"].detach(), str(cfg.dataset.type).lower() == "blender")
+                           head["left"].detach(), head["part"].detach(), dp_blender)
                 if torch.is_grad_enabled() and (weights_0.requires_grad or mus_0.requires_grad or sigmas_0.requires_grad):
                     dp = F.dp_loss(*dp_args)
                     dp_loss = (dp * (t_vals.shape[1] - 1) + mus_reg + sig_reg).unsqueeze(0)      # :287-289
+                elif dp_ws is not None:  # the row filter is in the workspace already (the fine compositing launch wrote it)
+                    dp_loss = ops.dp_loss_forward_kept(*dp_args[:-1], dp_ws, scal)[1]
                 else:  # nothing to differentiate: the record comes out of the loss kernel's last launch
                     dp_loss = ops.dp_loss_forward(*dp_args, reg_scal=scal)[1]
             # level 1 records the stale level-0 tensors under the level-0 mask, as the reference does (:297-300); the

@@ -374,6 +374,16 @@ def dp_loss_backward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender, g_loss):
 ACT_ROWS = 2560
 ROW_FEAT, ROW_DIR, ROW_X = 2048, 2304, 2432
 
+# Test hook: how the training kernels' record / sign-word buffers are allocated.  The kernels write every element a weight
+# gradient may read and mask the rest, so the product allocates uninitialised memory; the tests swap in an allocator that fills
+# the buffers with NaN patterns first (tests/test_hip_backward.py) -- deterministic, unlike hoping that the caching allocator hands
+# poisoned blocks back.
+RECORD_ALLOC = torch.empty
+
+
+def _record(shape, dtype, device):
+    return RECORD_ALLOC(shape, dtype=dtype, device=device)
+
 
 def mlp_f32_pack_t(params_flat, depth_head):
     params_flat = _f32c(params_flat, "params")
@@ -392,7 +402,7 @@ def mlp_f32_forward_train(feat, packed, depth_head, rec=False):
     M = feat.shape[0]
     ld = (M + 127) // 128 * 128
     raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
-    acts = torch.empty((ACT_ROWS, ld), dtype=torch.float32, device=feat.device)
+    acts = _record((ACT_ROWS, ld), torch.float32, feat.device)
 
     def launch():
         _lib.check(getattr(_lib.lib(), fn)(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts), M, ld, _stream()), fn)
@@ -410,7 +420,7 @@ def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head, rec=False):
     g_raw = _f32c(g_raw, "g_raw")
     M = g_raw.shape[0]
     ld = acts.shape[1]
-    deltas = torch.empty_like(acts)
+    deltas = _record(tuple(acts.shape), acts.dtype, acts.device)
     _lib.check(getattr(_lib.lib(), fn)(_ptr(g_raw), _ptr(packed_t), _ptr(acts), int(depth_head), _ptr(deltas), M, ld, _stream()), fn)
     return deltas
 
@@ -429,8 +439,8 @@ def mlp_x3_forward_train(feat, packed, depth_head):
     M = feat.shape[0]
     ld = (M + 127) // 128 * 128
     raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
-    acts = torch.empty((ACT_ROWS // 2, ld), dtype=torch.float32, device=feat.device)
-    bits = torch.empty((ACT_ROWS // 32 * 2, ld), dtype=torch.int16, device=feat.device)
+    acts = _record((ACT_ROWS // 2, ld), torch.float32, feat.device)
+    bits = _record((ACT_ROWS // 32 * 2, ld), torch.int16, feat.device)
 
     def launch():
         _lib.check(_lib.lib().ddnerf_mlp_x3_forward_train(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts),
@@ -448,7 +458,7 @@ def mlp_x3_backward_data(g_raw, packed_t, bits, depth_head):
     g_raw = _f32c(g_raw, "g_raw")
     M = g_raw.shape[0]
     ld = bits.shape[1]
-    deltas = torch.empty((ACT_ROWS // 2, ld), dtype=torch.float32, device=g_raw.device)
+    deltas = _record((ACT_ROWS // 2, ld), torch.float32, g_raw.device)
     _lib.check(_lib.lib().ddnerf_mlp_x3_backward_data(_ptr(g_raw), _ptr(packed_t), _ptr(bits), int(depth_head), _ptr(deltas),
                                                       M, ld, _stream()), "ddnerf_mlp_x3_backward_data")
     return deltas

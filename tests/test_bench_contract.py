@@ -46,7 +46,7 @@ def test_render_line_has_the_contract_fields():
     assert abs(clk["mfma_busy"] - clk["ideal_cycles_per_tile"] / clk["cycles_per_256_sample_tile"]) < 1e-3
     tt = d["train_tier"]
     assert tt["x3"]["value"] > tt["fp32"]["value"] > 0
-    assert abs(tt["x3"]["roofline"]["frac_issued"] - 3 * tt["x3"]["roofline"]["frac"]) < 2e-3
+    assert tt["x3"]["roofline"]["frac"] < tt["x3"]["roofline"]["frac_issued"] < 3 * tt["x3"]["roofline"]["frac"]
 
 
 def test_train_line():

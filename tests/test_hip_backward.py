@@ -121,7 +121,7 @@ def test_dp_loss_backward_well_conditioned_vs_fp64_autograd(ops, blender):
 
 @pytest.mark.parametrize("mlp_dtype", ["fp32", "x3"])
 @pytest.mark.parametrize("depth,M", [(True, 200), (False, 129), (True, 1000)])
-def test_mlp_backward_vs_autograd(ops, depth, M, mlp_dtype):
+def test_mlp_backward_vs_autograd(ops, monkeypatch, depth, M, mlp_dtype):
     """forward_train + backward_data + weight gradients of one network against torch autograd on the fp32 restatement;
     "x3" = the split-precision bf16-MFMA training kernels.  M = 129 is ragged (one sample past a 128-sample tile).
     x3 activations differ from fp32 ones by ~1e-6, so a pre-activation within that distance of 0 can land on the other side of
@@ -130,11 +130,14 @@ def test_mlp_backward_vs_autograd(ops, depth, M, mlp_dtype):
     from ddnerf_amd import functions as F
     from ddnerf_amd import base_architectures as BA
 
-    if M % 128:  # ragged: the records the kernels are about to allocate come out of NaN-filled memory -- pad columns (samples
-        # M .. ld) and rows nobody writes must not leak into a weight gradient
-        ld = (M + 127) // 128 * 128
-        poison = [torch.full((2560, ld), float("nan"), device="cuda") for _ in range(3)] + [torch.full((160, ld), -1, dtype=torch.int16, device="cuda")]
-        del poison
+    # every record / sign-word buffer the training kernels get is pre-filled with NaN patterns (all-ones words: a NaN as fp32, as a
+    # hi/lo word and as a bf16 pair): pad columns (samples M .. ld) and rows nobody writes must not leak into a weight gradient
+    def poisoned(shape, dtype, device):
+        t = torch.empty(shape, dtype=dtype, device=device)
+        t.view(torch.int16).fill_(-1)
+        return t
+
+    monkeypatch.setattr(ops, "RECORD_ALLOC", poisoned)
     g = torch.Generator().manual_seed(5)
     net = (BA.DepthMipNeRFModel if depth else BA.MipNeRFModel)(hidden_size=256, include_input_dir=True)
     sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(depth, 9, 3.0).items()}
@@ -162,8 +165,10 @@ def test_mlp_backward_vs_autograd(ops, depth, M, mlp_dtype):
             close(p.grad, ref, 1e-3, 2e-5 * float(ref.abs().max()))
         else:  # the x3 tier's weight gradients contract bf16-rounded activations and deltas (one MFMA per product, fp32 accumulation):
             # relative error ~2^-9 per product, measured 2.2e-3 of the norm; a wrong tile, row map or sign bit would be off by O(1)
+            # (a bias gradient is a plain sum of M bf16-rounded deltas with cancellation: 5e-3 measured at M = 129, shrinking with M)
             a, b = p.grad.double(), ref.double()
-            assert float((a - b).norm()) <= 4e-3 * float(b.norm()) + 1e-12, (name, float((a - b).norm() / b.norm()))
+            bar = 1e-2 if p.dim() == 1 else 4e-3
+            assert float((a - b).norm()) <= bar * float(b.norm()) + 1e-12, (name, float((a - b).norm() / b.norm()))
             assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), name
     # the parameter gradients are views of ONE flat buffer (the data-parallel bucket)
     flat = net.last_flat_grad

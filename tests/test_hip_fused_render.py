@@ -1,0 +1,136 @@
+"""The render path's folded launches against the one-kernel-per-reference-function entry points they replace: same arithmetic, same
+outputs (bit for bit, except the two L2 regularisers at nc != 64, whose partial sums are grouped differently).
+  ops.pack_rays_first_cycle  = pack_rays + sample_first_cycle                      (models/models.py:144-162, models/samplers.py:30-62)
+  ops.dd_coarse_forward      = dd_head + composite_forward + dd_records            (models/models.py:242-295)
+  ops.composite_forward_keep + dp_loss_forward_kept = composite_forward + dp_loss_forward   (models/dd_utils.py:16)"""
+import numpy as np
+import pytest
+import torch
+
+from ddnerf_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from ddnerf_amd import ops as _ops
+    return _ops
+
+
+def _rays(kind, n, seed):
+    ro, rd, rad, _ = synthetic.make_rays(kind, n, seed)
+    return tuple(torch.from_numpy(x).cuda() for x in (ro, rd, rad))
+
+
+@pytest.mark.parametrize("lindisp", [False, True])
+@pytest.mark.parametrize("n,nc", [(1, 4), (37, 64), (4096, 64), (300, 33)])
+def test_pack_rays_first_cycle(ops, n, nc, lindisp):
+    ro, rd, rad = _rays("real360" if lindisp else "blender", n, 3)
+    near, far = (0.2, 2.8) if lindisp else (2.0, 6.0)
+    t_lin = torch.linspace(0.0, 1.0, nc + 1).cuda()
+    for t_rand in (None, torch.rand(n, nc + 1, device="cuda")):
+        rays_a = ops.pack_rays(ro, rd, rad, near, far)
+        t_a = ops.sample_first_cycle(rays_a, t_lin, t_rand, lindisp)
+        rays_b, t_b = ops.pack_rays_first_cycle(ro, rd, rad, near, far, t_lin, t_rand, lindisp)
+        assert torch.equal(rays_a, rays_b) and torch.equal(t_a, t_b)
+
+
+def _coarse_inputs(n, nc, seed, kind="blender", zero_rows=False):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ro, rd, rad = _rays(kind, n, seed)
+    near, far = synthetic.NEAR_FAR[kind]
+    from ddnerf_amd import ops
+    rays = ops.pack_rays(ro, rd, rad, near, far)
+    t = torch.sort(torch.rand(n, nc + 1, device="cuda", generator=g) * (far - near) + near, dim=1)[0]
+    t[:, 0], t[:, -1] = near, far
+    raw = torch.randn(n, nc, 6, device="cuda", generator=g) * 3.0
+    if zero_rows:
+        raw[::5, :, 3] = -60.0          # softplus underflows: all-zero weight rows (0/0 pdf, dropped by the dp loss's filter)
+    return rays, t.contiguous(), raw.contiguous()
+
+
+@pytest.mark.parametrize("white,blender,with_noise", [(False, True, True), (True, True, False), (False, False, False), (True, False, True)])
+@pytest.mark.parametrize("n,nc", [(4096, 64), (37, 64), (50, 16), (9, 33), (130, 128)])
+def test_dd_coarse_forward_equals_its_parts(ops, n, nc, white, blender, with_noise):
+    rays, t, raw = _coarse_inputs(n, nc, 7 + n, zero_rows=True)
+    noise = torch.randn(n, nc, device="cuda") if with_noise else None
+    smooth, dist_reg = 1.7, 0.0156
+    head = ops.dd_head(raw, smooth, dist_reg)
+    c = ops.composite_forward(raw, t, rays, noise, head["mus"], white, blender)
+    rec = ops.dd_records(c["weights"], head["mus"], head["sigmas"], head["ssig"])
+    c2, head2, ticket = ops.dd_coarse_forward(raw, t, rays, noise, smooth, dist_reg, white, blender)
+    rec2 = ops.dd_records_finish(ticket)
+    for k in ("mus", "sigmas", "left", "part", "ssig", "sleft", "spart"):
+        assert torch.equal(head[k], head2[k]), k
+    if nc == 64:
+        assert torch.equal(head["scal"], head2["scal"])
+    else:
+        assert torch.allclose(head["scal"], head2["scal"], rtol=2e-6, atol=0)
+    for k in ("rgb_map", "disp", "acc", "weights", "depth", "cdisp"):
+        a, b = c[k], c2[k]
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), k
+    assert len(rec) == len(rec2) == 3
+    for a, b in zip(rec, rec2):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dp_blender", [True, False])
+@pytest.mark.parametrize("n,nc,nf", [(4096, 64, 128), (41, 16, 16), (10, 32, 48)])
+def test_fine_compositing_with_row_filter(ops, n, nc, nf, dp_blender):
+    rays, t0, raw0 = _coarse_inputs(n, nc, 3 + n)
+    _, t1, raw1 = _coarse_inputs(n, nf, 5 + n, zero_rows=True)
+    raw1 = raw1[..., :4].contiguous()
+    head = ops.dd_head(raw0, 1.7, 0.0156)
+    c0 = ops.composite_forward(raw0, t0, rays, None, head["mus"], False, True)
+    for blender in (True, False):
+        c1 = ops.composite_forward(raw1, t1, rays, None, None, False, blender)
+        args = (t1, t0, c1["weights"], c0["weights"], head["mus"], head["sigmas"], head["left"], head["part"])
+        loss_a, total_a = ops.dp_loss_forward(*args, dp_blender, reg_scal=head["scal"])
+        c1b, ws = ops.composite_forward_keep(raw1, t1, rays, None, None, False, blender, dp_blender)
+        loss_b, total_b = ops.dp_loss_forward_kept(*args[:2], c1b["weights"], *args[3:], ws, head["scal"])
+        for k in ("rgb_map", "disp", "acc", "weights", "depth"):
+            a, b = c1[k], c1b[k]
+            assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), k
+        assert torch.equal(loss_a, loss_b) and torch.equal(total_a, total_b)
+        keep = ws[: 4 * n].view(torch.int32)
+        want = (c1["weights"].sum(1) > 1e-10).int() if dp_blender else torch.ones(n, dtype=torch.int32, device="cuda")
+        assert int((keep != want).sum()) == 0 and (not dp_blender or int(keep.sum()) < n)      # the filter really drops rows
+
+
+@pytest.mark.parametrize("name", ["runiter_dd_blender_64x128_validation", "runiter_dd_llff_16x16_validation", "runiter_dd_real360_32x48_validation",
+                                  "runiter_mip_blender_64x128_validation"])
+def test_run_iter_same_outputs_with_and_without_folding(name):
+    """whole render pass, replayed random draws: the folded path (default) and the one-kernel-per-function path give identical dicts"""
+    from _cases import load_runiter
+    from ddnerf_amd import models as M
+    from test_hip_run_iter import build_model
+
+    c = load_runiter(name)
+    g = c["g"]
+    d = lambda x: torch.from_numpy(x).cuda()
+    outs = []
+    for fuse in (True, False):
+        M.FUSE_RENDER = fuse
+        try:
+            model = build_model(c)
+            model.eval()
+            with torch.no_grad():
+                outs.append(model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode="validation", rgb_target=d(g["tgt"])))
+        finally:
+            M.FUSE_RENDER = True
+    a, b = outs
+    assert a.keys() == b.keys()
+    for lvl in a:
+        assert a[lvl].keys() == b[lvl].keys()
+        for k in a[lvl]:
+            x, y = a[lvl][k], b[lvl][k]
+            assert (x is None) == (y is None), (lvl, k)
+            if x is not None:
+                assert x.shape == y.shape, (lvl, k)
+                if k in ("mus_loss", "sig_loss", "mus_reg", "sig_reg", "dp_loss") and c["nc"] != 64:
+                    # (the two L2 regularisers' partial sums are grouped per 4 rays instead of per 256 elements: same at nc = 64)
+                    assert torch.allclose(x, y, rtol=3e-6, atol=0), (lvl, k)
+                else:
+                    assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)), (lvl, k)
