@@ -67,6 +67,8 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-bf16-tier", action="store_true", help="skip the extra x3 / bf16 kernel measurements of the default run")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays of the same workload timed on the CPU oracle")
+    p.add_argument("--ramp", type=int, default=0, help="untimed steps BEFORE the W warm-up steps: the power-limited bf16 / x3 kernels need "
+                   "about 30 steps of sustained load before the chip's clock settles (3 warm-up steps: fine MLP 0.422 ms, 30 or more: 0.404)")
     args = p.parse_args(argv)
     kind, mlp, rays = CONFIGS[args.config]
     args.ray_kind = kind
@@ -222,11 +224,14 @@ def child_line(args, extra):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+TIER_RAMP = 40  # untimed steps in front of a tier's warm-up (see --ramp)
+
+
 def train_tier(args, mlp):
     """Training throughput (forward + backward + Adam per step) of the same workload, from a child run of
     `bench.py --mode train --mlp <mlp>`; reported beside the render headline, never as `value`."""
     try:
-        d = child_line(args, ["--mode", "train", "--mlp", mlp, "--steps", "5", "--warmup", "2"])
+        d = child_line(args, ["--mode", "train", "--mlp", mlp, "--steps", "5", "--warmup", "2", "--ramp", "5"])
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
     return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "roofline": d.get("roofline")}
@@ -240,11 +245,11 @@ def extra_tier(args, mlp):
     Measured by a child `bench.py --mlp <tier>` run, started before this process initialises the GPU (inside this process,
     behind the fp32 run, the launch-heavy bf16 step measures up to 4x slower; beside an idle parent context 1.6x)."""
     try:
-        d = child_line(args, ["--mlp", mlp, "--steps", str(args.steps), "--warmup", str(args.warmup)])
+        d = child_line(args, ["--mlp", mlp, "--steps", str(args.steps), "--warmup", str(args.warmup), "--ramp", str(TIER_RAMP)])
     except Exception as e:  # the headline must not die with a tier
         return {"error": "%s: %s" % (type(e).__name__, e)}
     roof = d["roofline"]
-    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "roofline": roof}
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "ramp_steps": TIER_RAMP, "roofline": roof}
 
 
 def cpu_baseline(args, cfg, sd_c, sd_f):
@@ -317,7 +322,7 @@ def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
     f.argtypes = [V, V, C.c_int, V, C.c_long, V]
     L.ddnerf_debug_set_stamps.argtypes = [V]
     n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-    stamps = torch.zeros(n_cu * 5, dtype=torch.int64, device=device)
+    stamps = torch.zeros(n_cu * 6, dtype=torch.int64, device=device)
     if L.ddnerf_mlp_bf16_pack(flat_params.data_ptr(), 0, packed.data_ptr(), st) or L.ddnerf_debug_set_stamps(stamps.data_ptr()):
         return None
     t0, n = time.time(), 0
@@ -333,7 +338,7 @@ def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 50
-    s = stamps.cpu().numpy().reshape(n_cu, 5).astype(np.float64)
+    s = stamps.cpu().numpy().reshape(n_cu, 6).astype(np.float64)
     s = s[s[:, 4] > 0]
     clk = float(np.median((s[:, 2] - s[:, 0]) / (s[:, 3] - s[:, 1]) * 100.0))
     cyc = float(np.median((s[:, 2] - s[:, 0]) / s[:, 4]))
@@ -418,7 +423,7 @@ def main(argv=None):
 
     def timed(step):
         """W untimed steps, then EXACTLY K steps between barrier + synchronize fences; max over ranks."""
-        for _ in range(args.warmup):
+        for _ in range(args.ramp + args.warmup):
             step()
         fence()
         timer.pairs.clear()
