@@ -48,7 +48,7 @@ CONFIGS = {
     "config_ff_mipnerf.yml": ("llff", "fp32", 4096),
     "config_360_mipnerf.yml": ("real360", "fp32", 8192),
 }
-KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h"],
                   "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
 
 
@@ -296,10 +296,11 @@ def cpu_baseline(args, cfg, sd_c, sd_f):
 
 def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
     """In-kernel clock and matrix-pipe busy share of the bf16 fine-MLP kernel (MI355X_MICROARCH.md, DVFS give-back item 6):
-    the DIAGNOSTIC build of the same kernel source (ddnerf_amd/csrc/libddnerf_diag.so, -DBF16_STAMP) runs back to back on random
+    the DIAGNOSTIC build of the same kernel sources (ddnerf_amd/csrc/libddnerf_diag.so, -DBF16_STAMP) runs back to back on random
     bf16 feature rows with this model's fine-network weights for >= `seconds`; every workgroup stamps s_memtime / s_memrealtime
-    around its tile loop.  clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, cycles per 256-sample tile against the 4820 MFMAs x
-    16 cycles the tile needs.  Runs after the timed region; nothing in the product library executes a stamp."""
+    around its tile loop.  clock = d(s_memtime) / d(s_memrealtime) x 100 MHz; cycles per tile against the MFMAs x 16 cycles the tile
+    needs (a wave issues 4820 per 256-sample tile of the one-group kernel, 9640 per 512-sample tile of the two-group kernel: at this
+    size ddnerf_mlp_bf16_forward runs the latter).  Runs after the timed region; nothing in the product library executes a stamp."""
     import ctypes as C
 
     import numpy as np
@@ -321,9 +322,12 @@ def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
     f = L.ddnerf_mlp_bf16_forward
     f.argtypes = [V, V, C.c_int, V, C.c_long, V]
     L.ddnerf_debug_set_stamps.argtypes = [V]
+    L.ddnerf_debug_set_stamps_g2.argtypes = [V]
     n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-    stamps = torch.zeros(n_cu * 6, dtype=torch.int64, device=device)
-    if L.ddnerf_mlp_bf16_pack(flat_params.data_ptr(), 0, packed.data_ptr(), st) or L.ddnerf_debug_set_stamps(stamps.data_ptr()):
+    stamps = {"g1": torch.zeros(n_cu * 6, dtype=torch.int64, device=device),
+              "g2": torch.zeros(n_cu * (6 + 160), dtype=torch.int64, device=device)}   # (+ the two-group build's per-period stamps)
+    if (L.ddnerf_mlp_bf16_pack(flat_params.data_ptr(), 0, packed.data_ptr(), st) or L.ddnerf_debug_set_stamps(stamps["g1"].data_ptr())
+            or L.ddnerf_debug_set_stamps_g2(stamps["g2"].data_ptr())):
         return None
     t0, n = time.time(), 0
     while time.time() - t0 < seconds:
@@ -338,16 +342,20 @@ def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 50
-    s = stamps.cpu().numpy().reshape(n_cu, 6).astype(np.float64)
+    which = "g2" if int(stamps["g2"][:6 * n_cu].abs().sum()) else "g1"
+    s = stamps[which][:6 * n_cu].cpu().numpy().reshape(n_cu, 6).astype(np.float64)
     s = s[s[:, 4] > 0]
     clk = float(np.median((s[:, 2] - s[:, 0]) / (s[:, 3] - s[:, 1]) * 100.0))
     cyc = float(np.median((s[:, 2] - s[:, 0]) / s[:, 4]))
-    ideal = 4820 * 16
-    return {"in_kernel_clock_mhz": round(clk), "nominal_clock_mhz": 2400, "cycles_per_256_sample_tile": round(cyc), "ideal_cycles_per_tile": ideal,
-            "mfma_busy": round(ideal / cyc, 4), "frac_bound_at_this_clock": round(clk / 2400.0, 4),
+    tile = 512 if which == "g2" else 256
+    ideal = 4820 * 16 * (tile // 256)
+    return {"kernel": "two groups per weight pass (mlp_bf16_g2.hip)" if which == "g2" else "one group (mlp_bf16.hip)",
+            "in_kernel_clock_mhz": round(clk), "nominal_clock_mhz": 2400, "tile_samples": tile, "cycles_per_tile": round(cyc),
+            "ideal_cycles_per_tile": ideal, "mfma_busy": round(ideal / cyc, 4), "frac_bound_at_this_clock": round(clk / 2400.0, 4),
             "back_to_back_launch_ms": round(ms, 4), "back_to_back_frac": round(FLOP_FINE * M / (ms * 1e-3) / 1e12 / PEAK["bf16"], 4),
-            "warm_launches": n, "how": "diagnostic stamp build of the same kernel source, random bf16 feature rows, after the timed region; "
-            "frac ~= mfma_busy x in_kernel_clock / nominal_clock (less launch prologue / tail)"}
+            "warm_launches": n, "how": "diagnostic stamp build of the same kernel sources, random bf16 feature rows, after the timed region; "
+            "frac ~= mfma_busy x in_kernel_clock / nominal_clock (less launch prologue / tail; the stamps themselves cost the diagnostic "
+            "build a few per cent of busy share)"}
 
 
 def kernel_source_digest(mlp):

@@ -27,7 +27,9 @@ SOURCES = {
     "mlp_x3_wgrad.hip": [],
     "mlp_x3_wgrad_packed.hip": [],
     # accumulators in arch VGPRs (the VALU re-pack reads them), B files in the accumulator half: see mlp_bf16.hip
-    "mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+    "mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_DISPATCH"],
+    # the two-groups-per-weight-pass build of the same kernel; its tile body is generated (csrc/gen_bf16_g2.py)
+    "mlp_bf16_g2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_DISPATCH"],
     # (no SLP vectoriser: it packs the two subtractions of the hi / lo split into v_pk_add_f32, which costs more issue time
     # beside MFMAs than two v_sub_f32)
     "mlp_x3_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
@@ -38,8 +40,13 @@ SOURCES = {
 
 # kernels whose matrix instructions are inline asm: the compiler's assembly is scanned for dependent pairs that sit closer
 # than the wait states nobody pads (csrc/check_asm_hazards.py); a violation fails the build
-CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel",
+CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_bf16_g2.hip": "mlp_bf16g2_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel",
            "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel", "mlp_x3_bwd.hip": "mlp_x3_bwd16_kernel"}
+
+
+# kernels whose tile body is one block of assembly that owns the whole vector register file from its first iteration on: the loop
+# that the compiler wraps around it must be scalar code only
+ASM_BODY = {"mlp_bf16_g2.hip"}
 
 
 def _compile_checked(cmd, src, obj, kernel, verbose):
@@ -59,6 +66,11 @@ def _compile_checked(cmd, src, obj, kernel, verbose):
         n, bad = check_asm_hazards.check(asm, kernel)
         if bad:
             raise RuntimeError("%s: %d dependent instruction pairs closer than the unpadded wait states, e.g.\n%s" % (src, len(bad), bad[0]))
+        if src in ASM_BODY:
+            stray = check_asm_hazards.check_scalar_shell(asm, kernel)
+            if stray:
+                raise RuntimeError("%s: the compiler placed vector instructions between the iterations of the assembly tile body, "
+                                   "whose registers they may overwrite, e.g. %s" % (src, stray[0]))
         if verbose:
             print("%s: %d MFMAs, no too-close dependent pair (straight-line scan + %d loop back-edge seams: not a proof, the bit-exact "
                   "GPU tests are the gate)" % (src, n, check_asm_hazards.check.seams), flush=True)
@@ -74,10 +86,12 @@ DIAG_SO = os.path.join(CSRC, "libddnerf_diag.so")
 
 
 def build_diag(force: bool = False, verbose: bool = False) -> str:
-    deps = [os.path.join(CSRC, f) for f in ("mlp_bf16.hip", "mlp_mfma16.inc", "mlp_bf16_common.h", "common.h", "api.hip")] + [__file__]
+    deps = [os.path.join(CSRC, f) for f in ("mlp_bf16.hip", "mlp_bf16_g2.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h", "common.h",
+                                            "api.hip")] + [__file__]
     if force or _stale(DIAG_SO, deps):
-        cmd = [HIPCC] + COMMON + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_STAMP", "-shared", os.path.join(CSRC, "mlp_bf16.hip"),
-                                  os.path.join(CSRC, "api.hip"), "-o", DIAG_SO]
+        generate(force, verbose)
+        cmd = [HIPCC] + COMMON + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_STAMP", "-DBF16_DISPATCH", "-shared", os.path.join(CSRC, "mlp_bf16.hip"),
+                                  os.path.join(CSRC, "mlp_bf16_g2.hip"), os.path.join(CSRC, "api.hip"), "-o", DIAG_SO]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -88,7 +102,20 @@ def _stale(target, deps):
     return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
 
+G2_TABLES = os.path.join(CSRC, "mlp_bf16_g2_tables.gen.inc")   # (written last by the generator, after the four tile bodies)
+
+
+def generate(force: bool = False, verbose: bool = False) -> None:
+    """generated sources: the tile body of mlp_bf16_g2.hip"""
+    gen = os.path.join(CSRC, "gen_bf16_g2.py")
+    if force or _stale(G2_TABLES, [gen]):
+        out = subprocess.check_output([sys.executable, gen, CSRC], text=True)
+        if verbose:
+            print(out.strip(), flush=True)
+
+
 def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    generate(force, verbose)
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc", ".py"))]
     hdrs += [os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
     objs, todo = [], []

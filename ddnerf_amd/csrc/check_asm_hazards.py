@@ -131,6 +131,29 @@ def _scan(ins):
     return len([1 for m, _, _ in ins if m.startswith("v_mfma")]), bad
 
 
+def check_scalar_shell(path, kernel):
+    """A kernel whose tile body is ONE inline-asm block that keeps its state in fixed vector registers across the iterations of a
+    compiler-written loop (mlp_bf16_g2.hip): every instruction of that kernel outside the asm block, from the first block on, must be
+    scalar.  Returns the offending lines."""
+    bad, on, inside, seen = [], False, False, False
+    for line in open(path):
+        if re.match(r"^_Z\w*%s\w*:" % kernel, line):
+            on, inside, seen = True, False, False
+            continue
+        if not on:
+            continue
+        t = line.strip()
+        if ";#ASMSTART" in t:
+            inside = seen = True
+        elif ";#ASMEND" in t:
+            inside = False
+        elif t.startswith("s_endpgm"):
+            on = False
+        elif seen and not inside and re.match(r"^(v_|ds_|buffer_|global_|flat_|scratch_)", t):
+            bad.append(t)
+    return bad
+
+
 if __name__ == "__main__":
     n, bad = check(sys.argv[1], *(sys.argv[2:3]))
     for b in bad[:20]:

@@ -1,0 +1,662 @@
+#!/usr/bin/env python3
+"""Generator of the bf16 MLP kernel "two groups per weight pass" (mlp_bf16_g2.hip): the whole tile body as ONE block of gfx950
+assembly with every register assigned here (`python gen_bf16_g2.py outdir`; ddnerf_amd/build.py runs it).
+
+Why a second kernel: the one-group kernel (mlp_bf16.hip) moves the complete weight image L2 -> LDS once per 256 samples (357 LDS-DMA
+pieces per wave and tile, 2.9 GB per launch at BASELINE size); on this power-limited part that stream is paid for in clock, not only
+in issue slots.  Here a workgroup owns 512 samples: every wave two GROUPS of 64.  A layer's weights are staged into LDS once and used
+by both groups, one after the other (pass g0, then pass g1): 389 pieces per wave and 512 samples, 54 % of the stream.
+
+Why assembly: the plan needs the register file to the last register -- three activation files of 128 registers (F0, F1 in the
+accumulator half, F2 in arch VGPRs: at layer l group 0 reads file in0 and writes the spare file, group 1 then reads in1 and writes
+in0, dead by then; the roles rotate with period three), a 48-register transient, two accumulator tile sets, the fragment ring.  hipcc's
+allocator at that pressure copies tuples around next to the MFMAs (wrong results: nothing pads VALU-write -> MFMA-read wait states
+around inline asm) and spills.  With fixed registers there is no allocator; the generator also keeps the books of the memory counters
+(every s_waitcnt below is the exact number of younger operations) and the hazard scan of the build (check_asm_hazards.py) reads the
+result like any other kernel.
+
+LDS: four slots of 36 KiB.  A 256-wide layer is four chunks of four 16-row slices; chunk j of layer l+1 replaces chunk j of layer l as
+soon as group 1 is done with it (DMA issued in the next period, first read three periods later); the skip layer (K = 352, six chunks of
+three slices) streams through the slots once per group.  One s_barrier per period (a chunk's blocks of one pass), preceded by
+s_waitcnt vmcnt(loads issued during this period): everything issued in earlier periods has then landed, for every wave.
+
+Encoded features (never kept): layer 0 reads them from where the previous tile's last pass parked them (group 0: the upper fragments
+of F1, free while the 128-wide dir layer is written; group 1: the transient T); the skip layer's xyz columns and the view directions are
+fetched again (L2 / MALL hits) into registers that are idle at that point, one or two passes ahead of their use.  The only fetch with
+less lead is group 1's xyz block: T is busy with group 0's until the last k-steps of pass (5, g0), ten k-steps before group 1's first
+block wants it (the k-steps of a block keep the one-group kernel's order: the two kernels are bit-identical)."""
+import os
+import sys
+from collections import defaultdict
+
+# ---- network -------------------------------------------------------------------------------------------------------
+K = [96, 256, 256, 256, 256, 352, 256, 256, 256, 288, 128]      # packed layers (mlp_mfma16.inc: kK)
+SLOT_BYTES = 36 * 1024
+NSLOT = 4
+DEPTH = 4        # A fragments are read this many k-steps ahead
+STAMP_BLOCKS = (8, 20)   # (diagnostic builds: the periods whose blocks get a stamp of their own, behind the period stamps)
+DMA_SPAN_NUM, DMA_SPAN_DEN = [int(x) for x in os.environ.get("G2_DMA_SPAN", "1/1").split("/")]   # the part of its issue period over which a chunk's LDS-DMA pieces are spread
+FEAT_ROW = 256   # bytes of one encoded sample (DDNERF_FEAT_LD bf16)
+TILE = 512
+
+
+def rowb(k):
+    return 2 * k + 32
+
+
+def slice_bytes(k):
+    return 16 * rowb(k) + 64
+
+
+# chunks in consumption order of ONE group's walk through the network: lists of (layer, block)
+CHUNKS = []
+for l in range(9):
+    if l == 5:
+        for j in range(0, 16, 3):
+            CHUNKS.append([(5, b) for b in range(j, min(16, j + 3))])
+    else:
+        for j in range(0, 16, 4):
+            CHUNKS.append([(l, b) for b in range(j, j + 4)])
+CHUNKS.append([(9, 0), (9, 1), (9, 2)])
+CHUNKS.append([(9, 3), (9, 4), (9, 5)])
+CHUNKS.append([(9, 6), (9, 7), (9, 8), (10, 0)])
+
+
+def chunk_layout(ch):
+    off, offs = 0, []
+    for (l, b) in ch:
+        offs.append(off)
+        off += slice_bytes(K[l])
+    size = (off + 4095) // 4096 * 4096
+    assert size <= SLOT_BYTES, (ch, size)
+    return offs, off, size
+
+
+def npw_of(ci):
+    return chunk_layout(CHUNKS[ci])[2] // 4096   # KiB pieces per wave
+
+
+IMG_OFF, _off = [], 0
+for ch in CHUNKS:
+    IMG_OFF.append(_off)
+    _off += chunk_layout(ch)[2]
+IMG_BYTES = _off
+
+# ---- passes and periods ----------------------------------------------------------------------------------------------
+# a PASS = one group walking the chunks of one layer (layers 9 + 10 together: key 9); a PERIOD = one chunk of one pass
+chunks_of_layer = {}
+for ci, ch in enumerate(CHUNKS):
+    chunks_of_layer.setdefault(min(l for l, _ in ch) if ch[0][0] != 10 else 9, []).append(ci)
+PASSES = [(l, g) for l in range(10) for g in (0, 1)]
+PERIODS = [(pi, ci) for pi, (l, g) in enumerate(PASSES) for ci in chunks_of_layer[l]]
+NPER = len(PERIODS)
+
+# instances: one load of a chunk; resident layers: one instance serves both groups' periods; layer 5: one per group
+INST = []
+for l in range(10):
+    cis = chunks_of_layer[l]
+    if l == 5:
+        for g in (0, 1):
+            for ci in cis:
+                INST.append(dict(chunk=ci, uses=[PERIODS.index((PASSES.index((5, g)), ci))]))
+    else:
+        for ci in cis:
+            INST.append(dict(chunk=ci, uses=[PERIODS.index((PASSES.index((l, 0)), ci)), PERIODS.index((PASSES.index((l, 1)), ci))]))
+INST.sort(key=lambda d: d["uses"][0])
+while len(INST) % NSLOT:   # (a dummy instance keeps the round-robin slot assignment the same in every tile)
+    INST.append(dict(chunk=None, uses=[]))
+for i, d in enumerate(INST):
+    d["slot"] = i % NSLOT
+real = [d for d in INST if d["chunk"] is not None]
+for i, d in enumerate(INST):
+    if d["chunk"] is None:
+        continue
+    j = i - NSLOT
+    while INST[j % len(INST)]["chunk"] is None:
+        j -= NSLOT
+    prev = INST[j % len(INST)]
+    free_after = prev["uses"][-1] - (NPER if j < 0 else 0)
+    d["issue"] = free_after + 1          # the period after the slot's previous occupant was read for the last time (negative: previous tile)
+    assert d["uses"][0] - d["issue"] >= 2, ("lead", i, d)
+ISSUE_IN = {}
+for d in real:
+    ISSUE_IN.setdefault(d["issue"] % NPER, []).append(d)
+    d["for_next_tile"] = d["issue"] < 0
+for p, lst in ISSUE_IN.items():
+    assert len(lst) == 1, ("two instances in one period", p)
+
+
+def inst_of(period):
+    for d in real:
+        if period in d["uses"]:
+            return d
+    raise KeyError(period)
+
+
+def files(l):
+    """(input of group 0, input of group 1, spare) at layer l >= 1"""
+    t = (0, 1, 2)
+    for _ in range(l - 1):
+        t = (t[2], t[0], t[1])
+    return t
+
+
+def out_file(l, g):
+    if l == 0:
+        return g           # layer 0: group 0 writes F0, group 1 F1
+    a, b, c = files(l)
+    return c if g == 0 else a
+
+
+# ---- registers ----------------------------------------------------------------------------------------------------------
+F_BASE = {0: ("a", 0), 1: ("a", 128), 2: ("v", 0)}
+V_T, V_ACC, V_RING, V_BIAS, V_RP = 128, 176, 208, 224, 232
+V_ABP, V_BBP, V_ABH, V_LANE16, V_VX, V_PF, V_LG16, V_VST, V_VST1, V_TMP0, V_TMP1, V_ZERO, V_STAMP = 240, 242, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254
+S_CUR, S_TB, S_TBN, S_RB, S_SWAVE, S_T0, S_T1, S_TIME, S_SEXEC = 84, 86, 87, 88, 89, 90, 91, 94, 96
+S_CLOBBER = list(range(84, 98))
+# asm operands: %0 feature rows (buffer resource)  %1 outputs (buffer resource)  %2 %3 weight image (address lo, hi)  %4 LDS base  %5 wave
+#               %6 tile  %7 tiles per round (grid size)  %8 first tile of this workgroup  %9 stamps of this workgroup (diagnostic)
+
+
+def reg(kind, r, n=1):
+    return "%s%d" % (kind, r) if n == 1 else "%s[%d:%d]" % (kind, r, r + n - 1)
+
+
+def frag(f, c, t):
+    kind, base = F_BASE[f]
+    return kind, base + 4 * (8 * c + t)
+
+
+def treg(c, q):
+    return "v", V_T + 4 * (3 * c + q)
+
+
+def acc(par, c):
+    return V_ACC + 16 * par + 4 * c
+
+
+class Gen:
+    def __init__(self, depth_head, stamp, carry=None):
+        self.depth_head, self.stamp = depth_head, stamp
+        self.rs = 24 if depth_head else 16          # bytes of one output row
+        self.out = []
+        self.vm = list(carry["vm"]) if carry else []        # outstanding vector-memory loads: (serial, "dma" | "x")
+        self.vm_serial = carry["serial"] if carry else 0
+        self.pending = dict(carry["pending"]) if carry else {}   # register key -> serial of the load that fills it
+        self.lg = []                                        # outstanding LDS reads (keys)
+        self.nmfma = 0
+
+    def e(self, s):
+        self.out.append("\t" + s)
+
+    def comment(self, s):
+        self.out.append("; " + s)
+
+    # ---- counters
+    # vmcnt: vector-memory LOADS retire in order on this architecture -- loads into registers and LDS-DMA pieces alike (hipcc's own wait
+    # insertion counts on exactly that for gfx9-family parts) -- while a store may retire at any time relative to them.  The queue below
+    # therefore holds the loads only; a wait for a load allows as many operations outstanding as there are YOUNGER LOADS, which is exact
+    # when no store is in flight and stricter than necessary when one is.
+    def vm_issue(self, kind, key=None):
+        self.vm_serial += 1
+        if kind != "store":
+            self.vm.append((self.vm_serial, kind))
+        if key is not None:
+            self.pending[key] = self.vm_serial
+        return self.vm_serial
+
+    def vm_wait_serial(self, serial, kind=None):
+        """every load up to `serial` has completed"""
+        if not self.vm or self.vm[0][0] > serial:
+            return
+        n = sum(1 for s_, _ in self.vm if s_ > serial)
+        self.e("s_waitcnt vmcnt(%d)" % min(n, 63))
+        cut = serial if n <= 63 else self.vm[len(self.vm) - 64][0]
+        self.vm = [x for x in self.vm if x[0] > cut]
+        self.pending = {k: s_ for k, s_ in self.pending.items() if s_ > cut}
+
+    def vm_need(self, key):
+        if key in self.pending:
+            self.vm_wait_serial(self.pending[key], "x")
+            self.pending.pop(key, None)
+
+    def lg_issue(self, key):
+        self.lg.append(key)
+
+    def lg_need(self, key):
+        if key in self.lg:
+            n = len(self.lg) - 1 - self.lg.index(key)
+            assert n <= 15
+            self.e("s_waitcnt lgkmcnt(%d)" % n)
+            self.lg = self.lg[len(self.lg) - n:] if n else []
+
+    def lg_flush(self):
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.lg = []
+
+    # ---- building blocks
+    def set_bases(self, par, rb, slot):
+        self.e("s_add_u32 s%d, %%4, %d" % (S_T0, slot))
+        self.e("v_add_u32 v%d, s%d, v%d" % (V_BBP + par, S_T0, V_LG16))
+        self.e("v_bfe_u32 v%d, v%d, 4, 4" % (V_TMP0, V_LANE16))       # lane & 15
+        self.e("v_mul_u32_u24 v%d, %d, v%d" % (V_TMP0, rb, V_TMP0))
+        self.e("v_add_u32 v%d, v%d, v%d" % (V_ABP + par, V_TMP0, V_BBP + par))
+
+    def set_base_h(self, rb, slot):
+        self.e("s_add_u32 s%d, %%4, %d" % (S_T0, slot))
+        self.e("v_bfe_u32 v%d, v%d, 4, 4" % (V_TMP0, V_LANE16))
+        self.e("v_mul_u32_u24 v%d, %d, v%d" % (V_TMP0, rb, V_TMP0))
+        self.e("v_add3_u32 v%d, v%d, v%d, s%d" % (V_ABH, V_TMP0, V_LG16, S_T0))
+
+    def x_load(self, dst, nxt, g, c, q, key):
+        """16 bytes of the feature row of sample (this / next tile, group g, column block c, this lane's row): 32-column group q.
+        The row offset goes through the bounds-checked voffset: rows past the end read as zero (their outputs are never stored)."""
+        kind, r = dst
+        self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, (g * 64 + c * 16) * FEAT_ROW))
+        self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
+        self.e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d nt" % (reg(kind, r, 4), V_TMP1, 64 * q))
+        self.vm_issue("x", key)
+
+    def prefetch(self, nxt, g, line):
+        """one 128-byte line of each feature row of group g (this / next tile) into the L2 / MALL: every lane touches one row; the loaded
+        word goes to a register nothing reads"""
+        self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, g * 64 * FEAT_ROW))
+        self.e("v_lshlrev_b32 v%d, 4, v%d" % (V_TMP1, V_LANE16))
+        self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_TMP1))
+        self.e("buffer_load_dword v%d, v%d, %%0, 0 offen offset:%d" % (V_PF, V_TMP1, 128 * line))
+        self.vm_issue("x")
+
+    def dma_setup(self, img, lds, npw):
+        self.e("s_mul_i32 s%d, s%d, %d" % (S_T0, S_SWAVE, npw))
+        self.e("s_add_u32 s%d, s%d, %d" % (S_T1, S_T0, img))
+        self.e("s_add_u32 s%d, %%2, s%d" % (S_CUR, S_T1))
+        self.e("s_addc_u32 s%d, %%3, 0" % (S_CUR + 1))
+        self.e("s_add_u32 s%d, s%d, %d" % (S_T1, S_T0, lds))
+        self.e("s_add_u32 m0, s%d, %%4" % S_T1)
+
+    def dma_piece(self, imm):
+        self.e("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d" % (V_LANE16, S_CUR, S_CUR + 1, imm))
+        self.vm_issue("dma")
+
+    def stamp_pass(self, p):
+        if not self.stamp:
+            return
+        self.e("s_memtime s[%d:%d]" % (S_TIME, S_TIME + 1))
+        self.lg_flush()
+        self.e("v_mov_b32 v%d, s%d" % (V_STAMP, S_TIME))
+        self.e("v_mov_b32 v%d, s%d" % (V_STAMP + 1, S_TIME + 1))
+        self.e("s_mov_b64 exec, s[%d:%d]" % (S_SEXEC, S_SEXEC + 1))
+        self.e("global_store_dwordx2 v%d, v[%d:%d], %%9 offset:%d" % (V_ZERO, V_STAMP, V_STAMP + 1, 8 * p))
+        self.vm_issue("store")
+        self.e("s_mov_b64 exec, -1")
+
+    def store_raw(self, g, parh, para):
+        """outputs of group g: heads tile parh (rows 0-2 rgb on lane group 0, rows 4-5 mu / sigma on lane group 1), alpha = row 128 of the
+        dir layer = its ninth block (tile para), register 0, lane group 0"""
+        self.e("s_nop 7")
+        self.e("s_nop 7")   # (16 wait states before anything but an MFMA reads an MFMA result)
+        for c in range(4):
+            self.e("v_mov_b32 v%d, v%d" % (acc(parh, c) + 3, acc(para, c)))
+        self.e("s_mov_b64 exec, 0xffff")
+        for c in range(4):
+            self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_RB, (g * 64 + c * 16) * self.rs))
+            self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP0, S_T0, V_VST))
+            self.e("buffer_store_dwordx4 %s, v%d, %%1, 0 offen" % (reg("v", acc(parh, c), 4), V_TMP0))
+            self.vm_issue("store")
+        if self.depth_head:
+            self.e("s_mov_b64 exec, 0xffff0000")
+            for c in range(4):
+                self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_RB, (g * 64 + c * 16) * self.rs))
+                self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP0, S_T0, V_VST1))
+                self.e("buffer_store_dwordx2 %s, v%d, %%1, 0 offen" % (reg("v", acc(parh, c), 2), V_TMP0))
+                self.vm_issue("store")
+        self.e("s_mov_b64 exec, -1")
+
+    # ---- the tile body
+    def build_blocks(self):
+        blocks, k0 = [], 0
+        for per, (pi, ci) in enumerate(PERIODS):
+            lk, g = PASSES[pi]
+            d = inst_of(per)
+            offs = chunk_layout(CHUNKS[ci])[0]
+            for bi, (l, b) in enumerate(CHUNKS[ci]):
+                nks = K[l] // 32
+                order = list(range(nks))
+                # (the k-steps of a block run in the one-group kernel's order: fp32 accumulation order is part of the bit-exact contract)
+                blocks.append(dict(l=l, b=b, g=g, lk=lk, period=per, K0=k0, order=order, lds=d["slot"] * SLOT_BYTES + offs[bi],
+                                   first=bi == 0, last=bi == len(CHUNKS[ci]) - 1, outf=out_file(min(l, 9), g) if l < 10 else None))
+                k0 += nks
+        for i, blk in enumerate(blocks):
+            blk["par"] = i & 1
+        assert len(blocks) % 2 == 0
+        return blocks, k0
+
+    def bsrc(self, blk, ks, c):
+        """(register kind, first register, key) of the B fragment of k-step ks, column block c"""
+        l, g = blk["l"], blk["g"]
+        if l == 0:
+            if g == 0:
+                return frag(1, c, 4 + ks) + (("F", 1, c, 4 + ks),)
+            return treg(c, ks) + (("T", c, ks),)
+        if l == 5 and ks >= 8:
+            return treg(c, ks - 8) + (("T", c, ks - 8),)
+        if l == 9 and ks == 8:
+            if g == 0:
+                return treg(c, 0) + (("T", c, 0),)
+            return frag(0, c, 4) + (("F", 0, c, 4),)
+        if l == 10:
+            f = out_file(9, g)
+        else:
+            a, b_, _ = files(l)
+            f = a if g == 0 else b_
+        return frag(f, c, ks) + (("F", f, c, ks),)
+
+    def repack_ops(self, p):
+        """the re-pack of block p's four tiles as single instructions, step-major (a column's dependent steps are four gaps apart)"""
+        l, b, par, outf = p["l"], p["b"], p["par"], p["outf"]
+        if not (l < 9 or (l == 9 and b < 8)):
+            return []
+        relu = l != 8            # fc_feat has no activation
+        kind, _ = F_BASE[outf]
+        ops = []
+
+        def dst(c, h):
+            k, r = frag(outf, c, b // 2)
+            return r + 2 * (b & 1) + h
+        steps = []
+        if kind == "a":
+            steps.append(lambda c, h: "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (V_RP + 2 * c + h, acc(par, c) + 2 * h, acc(par, c) + 2 * h + 1))
+            if relu:
+                steps.append(lambda c, h: "v_pk_max_i16 v%d, v%d, 0" % (V_RP + 2 * c + h, V_RP + 2 * c + h))
+            steps.append(lambda c, h: "v_accvgpr_write_b32 a%d, v%d" % (dst(c, h), V_RP + 2 * c + h))
+        elif relu:
+            steps.append(lambda c, h: "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (V_RP + 2 * c + h, acc(par, c) + 2 * h, acc(par, c) + 2 * h + 1))
+            steps.append(lambda c, h: "v_pk_max_i16 v%d, v%d, 0" % (dst(c, h), V_RP + 2 * c + h))
+        else:
+            steps.append(lambda c, h: "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (dst(c, h), acc(par, c) + 2 * h, acc(par, c) + 2 * h + 1))
+        for st in steps:
+            for h in range(2):
+                for c in range(4):
+                    ops.append(st(c, h))
+        return ops
+
+    def x_events(self, blk):
+        """feature fetches hosted by this block: ((k-step position, gap), "x", dst, next tile?, group, column block, feature group, key) and
+        ((position, gap), "pf", next tile?, group, line).  Every workgroup of the launch runs this schedule in step, so a fetch is a burst of
+        the whole chip: each is issued a pass or more ahead of its use, and the one that cannot be (group 1's xyz block: its registers are
+        busy until ten k-steps before) is preceded by a prefetch of its lines into the L2."""
+        lk, g, l, b = blk["lk"], blk["g"], blk["l"], blk["b"]
+        ev = []
+
+        def x(pos, dst, nxt, gg, c, q, key):
+            ev.append((pos, "x", dst, nxt, gg, c, q, key))
+        if lk == 4 and g == 0 and b < 12:        # xyz of group 0 for the skip layer (T idles through layers 1-4)
+            c, q = divmod(b, 3)
+            x((1, 0), treg(c, q), 0, 0, c, q, ("T", c, q))
+        if lk == 5 and g == 0 and b < 2:         # (lines of group 1's rows -> L2, see above)
+            ev.append(((1, 0), "pf", 0, 1, b))
+        # xyz of group 1: fragment q of T is free once the LAST block of pass (5, g0) has issued its k-step 8 + q
+        if lk == 5 and g == 0 and b == 15:
+            for q in range(2):
+                for c in range(4):
+                    x((9 + q, c), treg(c, q), 0, 1, c, q, ("T", c, q))
+        if lk == 5 and g == 1 and b == 0:
+            for c in range(4):
+                x((0, c), treg(c, 2), 0, 1, c, 2, ("T", c, 2))
+        # the NEXT tile's layer-0 input of group 1 -> T: fragments 1, 2 are free from here on, fragment 0 carries group 0's view directions
+        # through pass (9, g0)
+        if lk in (6, 7) and g == 0 and b % 4 == 0:
+            j = (lk - 6) * 4 + b // 4
+            c, q = j // 2, 1 + j % 2
+            x((1, 0), treg(c, q), 1, 1, c, q, ("T", c, q))
+        if lk == 7 and g == 1 and b in (0, 8):   # (lines of the next tile's group-0 rows -> L2 / MALL; group 1's were touched above)
+            ev.append(((1, 0), "pf", 1, 0, b // 8))
+        if lk == 8 and g == 0 and b < 4:         # view directions of group 0 for layer 9
+            x((1, 0), treg(b, 0), 0, 0, b, 3, ("T", b, 0))
+        if lk == 9 and g == 0 and l == 9 and b < 4:   # view directions of group 1: fragment 4 of F0 (layer 9 writes fragments 0-3 only)
+            x((1, 0), frag(0, b, 4), 0, 1, b, 3, ("F", 0, b, 4))
+        if lk == 9 and g == 1 and l == 9 and b < 6:   # the next tile's layer-0 input of group 0 -> F1[c][4..6], two fragments per block
+            for j in range(2):
+                c, q = divmod(2 * b + j, 3)
+                x((2 + j, 0), frag(1, c, 4 + q), 1, 0, c, q, ("F", 1, c, 4 + q))
+        if lk == 9 and g == 1 and l == 9 and b < 4:
+            x((1, 0), treg(b, 0), 1, 1, b, 0, ("T", b, 0))
+        return ev
+
+    def tile(self):
+        blocks, NK = self.build_blocks()
+        kstep_blk = []
+        for i, blk in enumerate(blocks):
+            kstep_blk += [(i, ks) for ks in blk["order"]]
+        per_ksteps = defaultdict(list)
+        for n, (i, ks) in enumerate(kstep_blk):
+            per_ksteps[blocks[i]["period"]].append(n)
+        # DMA pieces: the instance issued in a period, spread evenly over the period's k-steps
+        dma_at = defaultdict(list)
+        for per in range(NPER):
+            for d in ISSUE_IN.get(per, []):
+                npw = npw_of(d["chunk"])
+                ks_list = per_ksteps[per]
+                # (measured, bf16 fine pass: spread over the whole period 0.6726 of peak, over 3/4 0.6704, 1/2 0.6686, 1/3 0.6678 -- the
+                # workgroups of a launch run in step, so a denser issue is a burst on the L2 of every XCD)
+                span = len(ks_list) * DMA_SPAN_NUM // DMA_SPAN_DEN
+                for i in range(npw):
+                    dma_at[ks_list[(i * span) // npw]].append((d, i, npw))
+
+        # A chunk whose load was issued only two periods before its first use is certified by the barrier right in front of that use:
+        # nothing of it is read ahead across that barrier (the reads wait in `deferred` and follow the barrier)
+        late = {d["uses"][0] for d in real if d["uses"][0] - d["issue"] < 3}
+        state = dict(period=0, deferred=[])
+
+        def rd_a(n, now=False):
+            if n >= NK:
+                return
+            i, ks = kstep_blk[n]
+            blk = blocks[i]
+            if not now and blk["period"] in late and blk["period"] != state["period"]:
+                state["deferred"].append(("a", n))
+                return
+            base = V_ABH if blk["l"] == 10 else V_ABP + (blk["period"] & 1)
+            self.e("ds_read_b128 %s, v%d offset:%d" % (reg("v", V_RING + 4 * (n % DEPTH), 4), base, blk["lds"] % SLOT_BYTES + 64 * ks))
+            self.lg_issue(("ring", n))
+
+        def rd_bias(i, now=False):
+            blk = blocks[i]
+            if not now and blk["period"] in late and blk["period"] != state["period"]:
+                state["deferred"].append(("bias", i))
+                return
+            self.e("ds_read_b128 %s, v%d offset:%d" % (reg("v", V_BIAS + 4 * blk["par"], 4), V_BBP + (blk["period"] & 1),
+                                                       blk["lds"] % SLOT_BYTES + 16 * rowb(K[blk["l"]])))
+            self.lg_issue(("bias", i))
+
+        def centre(i, npw):
+            first = i // 8 * 8
+            return first + (4 if min(8, npw - first) > 4 else 0)
+
+        # ---- tile begin: the bases of period 0, the first fragments, block 0's bias tile
+        b0 = blocks[0]
+        self.set_bases(0, rowb(K[b0["l"]]), b0["lds"] // SLOT_BYTES * SLOT_BYTES)
+        for n in range(DEPTH - 1):
+            rd_a(n)
+        rd_bias(0)
+        period_mark = self.vm_serial
+        self.stamp_pass(0)
+        for i, blk in enumerate(blocks):
+            l, b, g, par, K0, order = blk["l"], blk["b"], blk["g"], blk["par"], blk["K0"], blk["order"]
+            nks = len(order)
+            kmax = nks if nks <= 4 else min(nks - 1, 7)
+            self.comment("---- block %d: layer %d block %d group %d (period %d)" % (i, l, b, g, blk["period"]))
+            gaps = defaultdict(list)
+            if blk["first"]:
+                period_mark = self.vm_serial
+                assert state["period"] == blk["period"]
+                nper = blk["period"] + 1
+                if nper < NPER:
+                    nb = next(x for x in blocks if x["period"] == nper)
+                    gaps[(0, 0)].append(("bases", nper & 1, rowb(K[nb["l"]]), nb["lds"] // SLOT_BYTES * SLOT_BYTES))
+                if any(x["l"] == 10 and x["period"] == blk["period"] for x in blocks):
+                    gaps[(0, 0)].append(("base_h", rowb(K[10]), blk["lds"] // SLOT_BYTES * SLOT_BYTES))
+            # re-pack of the previous block: one instruction per gap (gaps 1-3 of the first kmax k-steps)
+            ops = self.repack_ops(blocks[i - 1]) if i > 0 else []
+            slots = [(u, mi) for u in range(kmax) for mi in (1, 2, 3)]
+            for t, op in enumerate(ops):
+                gaps[slots[(t * len(slots)) // len(ops)]].append(("op", op))
+            # weight stream
+            for u in range(nks):
+                for j, (d, pi_, npw) in enumerate(dma_at.get(K0 + u, [])):
+                    assert j < 3
+                    if pi_ % 8 == 0:
+                        c0 = centre(pi_, npw)
+                        gaps[(u, j)].append(("dma_setup", IMG_OFF[d["chunk"]] + c0 * 1024, d["slot"] * SLOT_BYTES + c0 * 1024, npw))
+                    gaps[(u, j + 1)].append(("dma", (pi_ - centre(pi_, npw)) * 1024))
+            for it in self.x_events(blk):
+                gaps[it[0]].append(it[1:])
+            for u, ks in enumerate(order):
+                n = K0 + u
+                for mi in range(4):
+                    c = mi
+                    kind, r, key = self.bsrc(blk, ks, c)
+                    self.vm_need(key)
+                    if mi == 0:
+                        if u == 0:
+                            self.lg_need(("bias", i))
+                        self.lg_need(("ring", n))
+                    a_ = reg("v", V_RING + 4 * (n % DEPTH), 4)
+                    cc = reg("v", V_BIAS + 4 * par, 4) if u == 0 else reg("v", acc(par, c), 4)
+                    self.e("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (reg("v", acc(par, c), 4), a_, reg(kind, r, 4), cc))
+                    self.nmfma += 1
+                    if mi == 0:
+                        rd_a(n - 1 + DEPTH)
+                        if u == 1 and i + 1 < len(blocks):
+                            rd_bias(i + 1)
+                    for it in gaps.get((u, mi), []):
+                        if it[0] == "op":
+                            self.e(it[1])
+                        elif it[0] == "dma_setup":
+                            self.dma_setup(*it[1:])
+                        elif it[0] == "dma":
+                            self.dma_piece(it[1])
+                        elif it[0] == "x":
+                            self.x_load(*it[1:])
+                        elif it[0] == "pf":
+                            self.prefetch(*it[1:])
+                        elif it[0] == "bases":
+                            self.set_bases(*it[1:])
+                        elif it[0] == "base_h":
+                            self.set_base_h(*it[1:])
+            if blk["last"]:
+                # everything issued before this period began has landed once the loads of this period are all that is left
+                self.vm_wait_serial(period_mark, "dma")
+                self.e("s_barrier")
+                state["period"] = blk["period"] + 1
+                for kind_, x in state["deferred"]:
+                    (rd_a if kind_ == "a" else rd_bias)(x, True)
+                state["deferred"] = []
+            if l == 10:
+                self.store_raw(g, par, blocks[i - 1]["par"])
+            if STAMP_BLOCKS[0] <= blk["period"] < STAMP_BLOCKS[1]:
+                self.stamp_pass(NPER + 1 + sum(len(CHUNKS[PERIODS[p_][1]]) for p_ in range(STAMP_BLOCKS[0], blk["period"])) + [x for x in blocks if x["period"] == blk["period"]].index(blk))
+            if blk["last"]:
+                self.stamp_pass(blk["period"] + 1)          # (diagnostic builds: the clock at the end of every period; slot 0: tile begin)
+        self.lg_flush()
+        return blocks, NK
+
+    def prologue(self):
+        """first tile of a workgroup: lane constants, the chunks the steady state expects from "the previous tile", this tile's inputs"""
+        e = self.e
+        e("v_mbcnt_lo_u32_b32 v%d, -1, 0" % V_TMP0)
+        e("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (V_TMP0, V_TMP0))
+        e("v_lshlrev_b32 v%d, 4, v%d" % (V_LANE16, V_TMP0))
+        e("v_and_b32 v%d, 15, v%d" % (V_TMP1, V_TMP0))
+        e("v_lshrrev_b32 v%d, 4, v%d" % (V_LG16, V_TMP0))
+        e("v_lshlrev_b32 v%d, 4, v%d" % (V_LG16, V_LG16))
+        e("v_lshlrev_b32 v%d, 8, v%d" % (V_VX, V_TMP1))
+        e("v_add_u32 v%d, v%d, v%d" % (V_VX, V_VX, V_LG16))
+        e("v_mul_u32_u24 v%d, %d, v%d" % (V_VST, self.rs, V_TMP1))
+        e("v_add_u32 v%d, 16, v%d" % (V_VST1, V_VST))
+        e("v_mov_b32 v%d, 0" % V_ZERO)
+        pro = sorted([d for d in real if d["for_next_tile"]], key=lambda d: d["issue"])
+        for d in pro:
+            npw = npw_of(d["chunk"])
+            for i in range(npw):
+                c0 = i // 8 * 8 + (4 if min(8, npw - i // 8 * 8) > 4 else 0)
+                if i % 8 == 0:
+                    self.dma_setup(IMG_OFF[d["chunk"]] + c0 * 1024, d["slot"] * SLOT_BYTES + c0 * 1024, npw)
+                    e("s_nop 0")
+                e("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d" % (V_LANE16, S_CUR, S_CUR + 1, (i - c0) * 1024))
+        for c in range(4):
+            for q in range(3):
+                for (dst, g) in ((frag(1, c, 4 + q), 0), (treg(c, q), 1)):
+                    e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, (g * 64 + c * 16) * FEAT_ROW))
+                    e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
+                    e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d nt" % (reg(dst[0], dst[1], 4), V_TMP1, 64 * q))
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
+
+    def head(self):
+        e = self.e
+        e("s_lshl_b32 s%d, %%5, 10" % S_SWAVE)
+        e("s_lshl_b32 s%d, %%6, 17" % S_TB)           # tile * 512 rows * 256 bytes
+        e("s_lshl_b32 s%d, %%5, 15" % S_T0)           # wave * 128 rows
+        e("s_add_u32 s%d, s%d, s%d" % (S_TB, S_TB, S_T0))
+        e("s_lshl_b32 s%d, %%7, 17" % S_TBN)
+        e("s_add_u32 s%d, s%d, s%d" % (S_TBN, S_TBN, S_TB))
+        e("s_lshl_b32 s%d, %%6, 9" % S_RB)
+        e("s_lshl_b32 s%d, %%5, 7" % S_T0)
+        e("s_add_u32 s%d, s%d, s%d" % (S_RB, S_RB, S_T0))
+        e("s_mul_i32 s%d, s%d, %d" % (S_RB, S_RB, self.rs))
+        if self.stamp:
+            e("s_cmp_eq_u32 %5, 0")
+            e("s_cselect_b64 s[%d:%d], 1, 0" % (S_SEXEC, S_SEXEC + 1))
+        e("s_cmp_lg_u32 %6, %8")
+        e("s_cbranch_scc1 .Lsteady%=")
+        self.prologue()
+        self.out.append(".Lsteady%=:")
+
+
+def generate(depth_head, stamp):
+    g1 = Gen(depth_head, stamp)
+    g1.tile()                                                  # pass 1: what a tile leaves outstanding for the next one
+    carry = dict(vm=g1.vm, serial=g1.vm_serial, pending=g1.pending)
+    g2 = Gen(depth_head, stamp, carry)
+    g2.head()
+    blocks, NK = g2.tile()
+    g3 = Gen(depth_head, stamp, dict(vm=g2.vm, serial=g2.vm_serial, pending=g2.pending))   # (fixed point: pass 3 must repeat pass 2)
+    g3.head()
+    g3.tile()
+    strip = lambda out: [x for x in out]
+    assert [x for x in g3.out] == [x for x in g2.out], "the steady state of the counters is not a fixed point"
+    return g2, blocks, NK
+
+
+def tables(blocks):
+    t = []
+    slices = []
+    for ci, ch in enumerate(CHUNKS):
+        offs = chunk_layout(ch)[0]
+        for (l, b), o in zip(ch, offs):
+            slices.append((l, b, IMG_OFF[ci] + o))
+    t.append("#define G2_IMG_BYTES %d" % IMG_BYTES)
+    t.append("#define G2_NSLICE %d" % len(slices))
+    t.append("static constexpr int kG2Slice[G2_NSLICE][3] = {%s};" % ", ".join("{%d, %d, %d}" % s for s in slices))
+    regs = ['"v%d"' % i for i in range(256)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in S_CLOBBER]
+    t.append("#define G2_CLOBBERS %s, \"vcc\", \"scc\", \"memory\"" % ", ".join(regs))
+    return t
+
+
+if __name__ == "__main__":
+    outdir = sys.argv[1]
+    nlines = 0
+    for depth_head in (0, 1):
+        for stamp in (0, 1):
+            g, blocks, NK = generate(depth_head, stamp)
+            with open(os.path.join(outdir, "mlp_bf16_g2_body_d%d%s.gen.inc" % (depth_head, "s" if stamp else "")), "w") as f:
+                # (one string literal per line: clang locates every line of an asm string by re-lexing its token from the start, which
+                # on one megabyte-long literal takes minutes)
+                f.write("".join('"%s\\n"\n' % x for x in g.out))
+            nlines = len(g.out)
+    with open(os.path.join(outdir, "mlp_bf16_g2_tables.gen.inc"), "w") as f:
+        f.write("\n".join(tables(blocks)) + "\n")
+    total_pieces = sum(npw_of(d["chunk"]) for d in real)
+    print("gen_bf16_g2: %d blocks, %d k-steps (%d MFMAs), %d periods, %d chunk loads, %d pieces per wave per 512-sample tile (one-group kernel: 714), "
+          "image %d bytes, %d lines per body" % (len(blocks), NK, g.nmfma, NPER, len(real), total_pieces, IMG_BYTES, nlines))

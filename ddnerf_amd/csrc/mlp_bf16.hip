@@ -33,7 +33,13 @@
 // when spread evenly, about two per MFMA.
 #include "common.h"
 #define M16_PLANES 1
+// (in the library this kernel is ddnerf_mlp_bf16g1_*: ddnerf_mlp_bf16_* picks between it and the two-group kernel by launch size,
+// mlp_bf16_g2.hip; a stand-alone build of this file for A/B timing exports it as ddnerf_mlp_bf16_* itself)
+#ifdef BF16_DISPATCH
+#define M16_SYM(x) ddnerf_mlp_bf16g1_##x
+#else
 #define M16_SYM(x) ddnerf_mlp_bf16_##x
+#endif
 #define M16_KERNEL mlp_bf16_fwd_kernel
 #define M16_FEAT_T void
 #define M16_PACK_KERNEL mlp_bf16_pack_kernel

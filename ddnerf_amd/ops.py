@@ -118,6 +118,49 @@ def mlp_bf16_forward(feat, packed, depth_head):
     return raw
 
 
+def _bf16_variant_pack(which, params_flat, depth_head):
+    params_flat = _f32c(params_flat, "params")
+    L = _lib.lib()
+    packed = torch.empty(getattr(L, "ddnerf_mlp_%s_packed_bytes" % which)(int(depth_head)), dtype=torch.uint8, device=params_flat.device)
+    _lib.check(getattr(L, "ddnerf_mlp_%s_pack" % which)(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()), "ddnerf_mlp_%s_pack" % which)
+    return packed
+
+
+def _bf16_variant_forward(which, feat, packed, depth_head):
+    if not (feat.is_cuda and feat.dtype == torch.bfloat16 and feat.is_contiguous()):
+        raise _lib.DDNerfHipError("mlp_%s_forward wants a contiguous bf16 GPU feature tensor" % which)
+    M = feat.shape[0]
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+
+    def launch():
+        _lib.check(getattr(_lib.lib(), "ddnerf_mlp_%s_forward" % which)(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), M, _stream()),
+                   "ddnerf_mlp_%s_forward" % which)
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw
+
+
+# The two kernels behind mlp_bf16_forward by name (it picks by launch size; they produce the same bits for the same sample):
+# "g1" a workgroup owns 256 samples (mlp_bf16.hip), "g2" 512 samples as two groups per wave (mlp_bf16_g2.hip); each has its own image.
+def mlp_bf16g1_pack(params_flat, depth_head):
+    return _bf16_variant_pack("bf16g1", params_flat, depth_head)
+
+
+def mlp_bf16g1_forward(feat, packed, depth_head):
+    return _bf16_variant_forward("bf16g1", feat, packed, depth_head)
+
+
+def mlp_bf16g2_pack(params_flat, depth_head):
+    return _bf16_variant_pack("bf16g2", params_flat, depth_head)
+
+
+def mlp_bf16g2_forward(feat, packed, depth_head):
+    return _bf16_variant_forward("bf16g2", feat, packed, depth_head)
+
+
 def mlp_x3_pack(params_flat, depth_head):
     params_flat = _f32c(params_flat, "params")
     nbytes = _lib.lib().ddnerf_mlp_x3_packed_bytes(int(depth_head))

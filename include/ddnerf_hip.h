@@ -87,11 +87,24 @@ int ddnerf_mlp_f32_forward(const float *feat, const float *packed, int depth_hea
 /* bf16-MFMA variant of the same network (bf16 operands, fp32 accumulation, fp32 biases and outputs).
  * feat: bf16 [M,128] as written by ddnerf_encode(feat_dtype=1), i.e. in MFMA "k-order": inside every 32
  * columns, position 8g + e (g = 0..3, e = 0..7) holds column 16(e>>2) + 4g + (e&3) -- the order in which two
- * 16x16 accumulator tiles re-enter the next layer's v_mfma_f32_16x16x32_bf16 as its B operand. */
+ * 16x16 accumulator tiles re-enter the next layer's v_mfma_f32_16x16x32_bf16 as its B operand.
+ * Two kernels stand behind these three entry points and produce the same bits for the same sample: the forward picks by launch
+ * size (M >= 65536, or the value of the environment variable DDNERF_BF16_G2_MIN: the two-group kernel), the weight image holds
+ * both kernels' layouts. */
 size_t ddnerf_mlp_bf16_packed_bytes(int depth_head);
 int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M,
                             ddnerf_stream_t stream);
+/* ... the one-group kernel (mlp_bf16.hip): a workgroup owns 256 samples, every wave 64; its own weight image */
+size_t ddnerf_mlp_bf16g1_packed_bytes(int depth_head);
+int ddnerf_mlp_bf16g1_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_bf16g1_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
+/* ... the two-group kernel (mlp_bf16_g2.hip, tile body generated as assembly by gen_bf16_g2.py): a workgroup owns 512 samples, every
+ * wave two groups of 64; a layer's weights are staged into LDS once per tile and used by both groups (54 % of the L2 -> LDS weight
+ * stream per sample); its own weight image */
+size_t ddnerf_mlp_bf16g2_packed_bytes(int depth_head);
+int ddnerf_mlp_bf16g2_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
 
 /* K2 "x3": the same network on the bf16 matrix cores at fp32-class accuracy -- every fp32 weight and activation is split
  * exactly into hi + lo bf16, three MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulation: outputs within ~1e-6

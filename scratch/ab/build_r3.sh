@@ -10,6 +10,7 @@ for v in "$@"; do
     x3_old) b x3_old -fno-slp-vectorize $OLD/mlp_x3_fwd.hip $OLD/api.hip & ;;
     bf16_new) b bf16_new $C/mlp_bf16.hip $C/api.hip & ;;
     x3_new) b x3_new -fno-slp-vectorize $C/mlp_x3_fwd.hip $C/api.hip & ;;
+    g2_*) name=$v; d=${v#g2_}; [ "$d" = "new" ] && d=""; b $name $(echo "$d" | tr ',' ' ') $C/mlp_bf16_g2.hip $C/api.hip & ;;
     bf16_*) name=$v; d=${v#bf16_}; b $name $(echo "$d" | tr ',' ' ') $C/mlp_bf16.hip $C/api.hip & ;;
     x3_*) name=$v; d=${v#x3_}; b $name -fno-slp-vectorize $(echo "$d" | tr ',' ' ') $C/mlp_x3_fwd.hip $C/api.hip & ;;
   esac

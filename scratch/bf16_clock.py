@@ -19,7 +19,7 @@ packed = torch.empty(L.ddnerf_mlp_bf16_packed_bytes(0), dtype=torch.uint8, devic
 L.ddnerf_mlp_bf16_pack.argtypes = [V, C.c_int, V, V]
 assert L.ddnerf_mlp_bf16_pack(flat.data_ptr(), 0, packed.data_ptr(), st) == 0
 f = L.ddnerf_mlp_bf16_forward; f.argtypes = [V, V, C.c_int, V, C.c_long, V]
-stamps = torch.zeros(256 * 5, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(256 * 6, dtype=torch.int64, device="cuda")
 L.ddnerf_debug_set_stamps.argtypes = [V]
 assert L.ddnerf_debug_set_stamps(stamps.data_ptr()) == 0
 t0 = time.time(); n = 0
@@ -31,7 +31,7 @@ e0.record()
 for _ in range(50): f(fb.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 50
-s = stamps.cpu().numpy().reshape(256, 5).astype(np.float64)
+s = stamps.cpu().numpy().reshape(256, 6).astype(np.float64)
 clk = (s[:, 2] - s[:, 0]) / (s[:, 3] - s[:, 1]) * 100.0
 cyc = (s[:, 2] - s[:, 0]) / s[:, 4]
 print("launch %.4f ms (%.3f of the bf16 MFMA peak) after %d warm launches; in-kernel clock median %.0f MHz (min %.0f, max %.0f); "

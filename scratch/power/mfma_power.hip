@@ -1,0 +1,150 @@
+// What sustains the matrix pipe under the power limit?  Back-to-back bf16 MFMAs on resident operands, one wave per SIMD on every CU,
+// ~0.4 s per variant; prints achieved TFLOP/s and the in-kernel shader clock.   hipcc --offload-arch=gfx950 -O3 mfma_power.hip -o mfma_power
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// MODE 0: 16x16x32, operands in registers (8 B fragments rotate, 1 A per 4 MFMAs from registers)
+// MODE 1: 16x16x32, A re-read from LDS every 4 MFMAs (ds_read_b128), like the MLP kernel
+// MODE 2: 32x32x16, operands in registers
+// MODE 3: 32x32x16, A re-read from LDS every 2 MFMAs
+#ifndef UNR
+#define UNR 384
+#endif
+// MODE 4: as MODE 0, but the loop body is UNR x 64 MFMAs of straight-line code (UNR = 384: 196 KB, three times the instruction cache)
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k(const bf16x8 *__restrict__ src, float *__restrict__ out, int iters, unsigned long long *stamps) {
+    __shared__ bf16x8 lds[64 * 64];  // 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 64 * 64; i += 256) lds[i] = src[i];
+    __syncthreads();
+    bf16x8 b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = src[4096 + 64 * i + lane + 512 * (tid >> 6)];
+    bf16x8 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = lds[64 * i + lane];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if constexpr (MODE == 4) {
+        f32x4 acc[8] = {};
+        for (int it = 0; it < iters / UNR; ++it) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    bf16x8 av = a[s & 3];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[4 * (s & 1) + c]) : "v"(av), "v"(b[(c + s) & 7]));
+                }
+            }
+        }
+        f32x4 s = {};
+        asm volatile("s_nop 7\n\ts_nop 7");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += acc[i];
+        out[(size_t)blockIdx.x * 256 + tid] = s[0] + s[1] + s[2] + s[3];
+    } else if constexpr (MODE < 2) {
+        f32x4 acc[8] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {  // 16 k-steps x 4 MFMAs
+                bf16x8 av = a[s & 3];
+                if constexpr (MODE == 1) a[(s + 2) & 3] = lds[((it * 16 + s) & 63) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[4 * (s & 1) + c]) : "v"(av), "v"(b[(c + s) & 7]));
+            }
+        }
+        f32x4 s = {};
+        asm volatile("s_nop 7\n\ts_nop 7");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += acc[i];
+        out[(size_t)blockIdx.x * 256 + tid] = s[0] + s[1] + s[2] + s[3];
+    } else {
+        f32x16 acc[4] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {  // 16 k-steps x 2 MFMAs (same flops as above)
+                bf16x8 av = a[s & 3];
+                if constexpr (MODE == 3) a[(s + 2) & 3] = lds[((it * 16 + s) & 63) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[2 * (s & 1) + c]) : "v"(av), "v"(b[(c + s) & 7]));
+            }
+        }
+        f32x16 s = {};
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[i];
+        float t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += s[i];
+        out[(size_t)blockIdx.x * 256 + tid] = t;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+template <int MODE>
+static void run(const char *name, const bf16x8 *src, float *out, unsigned long long *stamps, int ncu, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9f, last = 0;
+    for (int rep = 0; rep < 12; ++rep) {  // ~12 x 40 ms back to back: the clock settles
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k<MODE>, dim3(ncu), dim3(256), 0, 0, src, out, iters, stamps);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&last, e0, e1);
+        if (last < best) best = last;
+    }
+    std::vector<unsigned long long> h(2 * ncu);
+    hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    double mhz = 0;
+    for (int i = 0; i < ncu; ++i) mhz += (double)h[2 * i] / ((double)h[2 * i + 1] / 100.0);  // memrealtime: 100 MHz
+    mhz /= ncu;
+    const double flops = (double)ncu * 4 * iters * 64.0 * 16384.0;
+    printf("%-44s last %.3f ms (%.0f TFLOP/s, %.3f of 2500)  best %.3f ms  clock %.0f MHz  busy %.1f %%\n", name, last, flops / last / 1e9, flops / last / 1e9 / 2500.0,
+           best, mhz, 100.0 * (iters * 64.0 * 16.0) / ((double)h[0]));
+}
+
+int main(int argc, char **argv) {
+    const int zero = argc > 1 ? atoi(argv[1]) : 0;
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int ncu = p.multiProcessorCount;
+    std::vector<unsigned short> h((4096 + 2048) * 8);
+    srand(1);
+    for (auto &v : h) {
+        float f = zero == 1 ? 0.0f : ((float)rand() / RAND_MAX * 2 - 1) * (zero == 2 ? 1e-3f : 1.0f);
+        if (zero == 3 && (rand() & 1)) f = 0.0f;  // half the values zero (post-ReLU activations)
+        unsigned u;
+        memcpy(&u, &f, 4);
+        v = (unsigned short)(u >> 16);
+    }
+    bf16x8 *src;
+    float *out;
+    unsigned long long *stamps;
+    hipMalloc(&src, h.size() * 2);
+    hipMalloc(&out, (size_t)ncu * 256 * 4);
+    hipMalloc(&stamps, ncu * 16);
+    hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    const int iters = 60000;  // 60000 x 64 MFMAs x 16 cycles = 61 M cycles ~ 30 ms
+    printf("data: %s, %d CUs\n", zero == 0 ? "uniform(-1,1)" : zero == 1 ? "zeros" : zero == 2 ? "uniform*1e-3" : "half zeros", ncu);
+    run<0>("16x16x32 registers", src, out, stamps, ncu, iters);
+    run<4>("16x16x32 registers, straight-line 196 KB", src, out, stamps, ncu, iters / UNR * UNR);
+    run<1>("16x16x32 A from LDS (1 ds_read_b128 / 4 MFMA)", src, out, stamps, ncu, iters);
+    run<2>("32x32x16 registers", src, out, stamps, ncu, iters);
+    run<3>("32x32x16 A from LDS (1 ds_read_b128 / 2 MFMA)", src, out, stamps, ncu, iters);
+    return 0;
+}

@@ -43,7 +43,7 @@ def test_render_line_has_the_contract_fields():
     # the bf16 line carries what its fraction is made of: the in-kernel clock and the matrix-pipe busy share (diagnostic build)
     clk = d["bf16_tier"]["roofline"]["clock"]
     assert 1000 < clk["in_kernel_clock_mhz"] <= 2500 and 0.5 < clk["mfma_busy"] <= 1.0
-    assert abs(clk["mfma_busy"] - clk["ideal_cycles_per_tile"] / clk["cycles_per_256_sample_tile"]) < 1e-3
+    assert abs(clk["mfma_busy"] - clk["ideal_cycles_per_tile"] / clk["cycles_per_tile"]) < 1e-3
     tt = d["train_tier"]
     assert tt["x3"]["value"] > tt["fp32"]["value"] > 0
     assert tt["x3"]["roofline"]["frac"] < tt["x3"]["roofline"]["frac_issued"] < 3 * tt["x3"]["roofline"]["frac"]

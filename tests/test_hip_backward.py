@@ -164,10 +164,11 @@ def test_mlp_backward_vs_autograd(ops, monkeypatch, depth, M, mlp_dtype):
         if mlp_dtype == "fp32":
             close(p.grad, ref, 1e-3, 2e-5 * float(ref.abs().max()))
         else:  # the x3 tier's weight gradients contract bf16-rounded activations and deltas (one MFMA per product, fp32 accumulation):
-            # relative error ~2^-9 per product, measured 2.2e-3 of the norm; a wrong tile, row map or sign bit would be off by O(1)
+            # each factor is off by at most 2^-9 relative, a product by at most 2^-8 = 3.9e-3; measured 2.2e-3 of the norm on the 256-row
+            # layers, 4.7e-3 on the single-row fc_alpha at M = 129 (little averaging); a wrong tile, row map or sign bit would be off by O(1)
             # (a bias gradient is a plain sum of M bf16-rounded deltas with cancellation: 5e-3 measured at M = 129, shrinking with M)
             a, b = p.grad.double(), ref.double()
-            bar = 1e-2 if p.dim() == 1 else 4e-3
+            bar = 1e-2 if p.dim() == 1 else 2.0 ** -7
             assert float((a - b).norm()) <= bar * float(b.norm()) + 1e-12, (name, float((a - b).norm() / b.norm()))
             assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), name
     # the parameter gradients are views of ONE flat buffer (the data-parallel bucket)

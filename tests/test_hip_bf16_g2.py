@@ -1,0 +1,75 @@
+"""The two bf16 MLP kernels behind ddnerf_mlp_bf16_forward -- one 64-sample group per wave (mlp_bf16.hip) and two groups per weight pass
+(mlp_bf16_g2.hip, tile body generated as assembly) -- run the same arithmetic in the same order: their outputs are compared BIT FOR
+BIT, on ragged sizes, one tile, several tiles per workgroup (the steady-state path of the persistent loop: its memory-counter
+bookkeeping, the features parked for the next tile) and both heads.  The entry point that picks between them by launch size must
+therefore give results that do not depend on the size of the launch a sample travels in."""
+import numpy as np
+import pytest
+import torch
+
+from ddnerf_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from ddnerf_amd import ops as _ops
+    return _ops
+
+
+def _flat(depth, seed, sharpen):
+    sd = synthetic.make_state_dict(depth, seed, sharpen)
+    names = [n for n, _, _ in synthetic.layer_table(depth)]
+    return torch.from_numpy(np.concatenate([np.concatenate([sd[k + ".weight"].ravel(), sd[k + ".bias"].ravel()]) for k in names])).cuda()
+
+
+def _rows(ops, M, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    feat = torch.zeros(M, 128, device="cuda")
+    feat[:, :123] = torch.rand(M, 123, device="cuda", generator=g) * 2 - 1
+    return feat[:, torch.as_tensor(ops.K_ORDER, device="cuda")].to(torch.bfloat16).contiguous()
+
+
+@pytest.mark.parametrize("depth", [False, True])
+def test_two_group_kernel_bit_identical_to_one_group(ops, depth):
+    flat = _flat(depth, 12, 20.0)      # (sharpened weights: activations of every magnitude, ReLU zeros in every layer)
+    p1, p2 = ops.mlp_bf16g1_pack(flat, depth), ops.mlp_bf16g2_pack(flat, depth)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    # 1 / 37: one ragged tile; 512, 513: the tile boundary; 3 tiles on 3 workgroups; every workgroup 2 tiles + a ragged one;
+    # BASELINE's fine pass (4096 x 128: four tiles per workgroup on 256 CUs)
+    for M in (1, 37, 512, 513, 3 * 512 - 5, 2 * 512 * n_cu + 77, 524288):
+        fb = _rows(ops, M, M)
+        a, b = ops.mlp_bf16g1_forward(fb, p1, depth), ops.mlp_bf16g2_forward(fb, p2, depth)
+        torch.cuda.synchronize()
+        assert a.shape == b.shape == (M, 6 if depth else 4)
+        assert torch.equal(a, b), (M, depth, int((a != b).any(dim=1).sum()), float((a - b).abs().max()))
+
+
+def test_two_group_kernel_is_deterministic_and_leaves_its_neighbours_alone(ops):
+    """the outputs go through a bounds-checked buffer: nothing is written past row M - 1, nothing depends on what follows the rows"""
+    flat = _flat(True, 5, 4.0)
+    p2 = ops.mlp_bf16g2_pack(flat, True)
+    M = 70001
+    fb_big = _rows(ops, M + 600, 3)
+    fb = fb_big[:M].contiguous()
+    a = ops.mlp_bf16g2_forward(fb, p2, True)
+    b = ops.mlp_bf16g2_forward(fb, p2, True)
+    c = ops.mlp_bf16g2_forward(fb_big, p2, True)[:M]     # the same rows inside a longer launch (other tile count, other neighbours)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_entry_point_picks_by_size_and_the_choice_is_invisible(ops, monkeypatch):
+    """ddnerf_mlp_bf16_forward: one weight image for both kernels; a sample's result does not depend on the launch it is part of"""
+    flat = _flat(False, 9, 1.0)
+    packed = ops.mlp_bf16_pack(flat, False)
+    p1 = ops.mlp_bf16g1_pack(flat, False)
+    assert packed.numel() > p1.numel() + 1_000_000        # (both images)
+    fb = _rows(ops, 100000, 7)
+    big = ops.mlp_bf16_forward(fb, packed, False)                      # >= 65536 samples: the two-group kernel
+    small = torch.cat([ops.mlp_bf16_forward(fb[i:i + 20000].contiguous(), packed, False) for i in range(0, 100000, 20000)])
+    ref = ops.mlp_bf16g1_forward(fb, p1, False)
+    torch.cuda.synchronize()
+    assert torch.equal(big, small) and torch.equal(big, ref)
