@@ -67,13 +67,18 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-bf16-tier", action="store_true", help="skip the extra x3 / bf16 kernel measurements of the default run")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays of the same workload timed on the CPU oracle")
-    p.add_argument("--ramp", type=int, default=0, help="untimed steps BEFORE the W warm-up steps: the power-limited bf16 / x3 kernels need "
-                   "about 30 steps of sustained load before the chip's clock settles (3 warm-up steps: fine MLP 0.422 ms, 30 or more: 0.404)")
+    p.add_argument("--ramp", type=int, default=None, help="untimed steps BEFORE the W warm-up steps: the power-limited bf16 / x3 kernels need "
+                   "about 30 steps of sustained load before the chip's clock settles (3 warm-up steps: fine MLP 0.422 ms, 30 or more: 0.404); "
+                   "default 40 for the bf16 / x3 render pass, 0 otherwise")
+    p.add_argument("--no-clock", action="store_true", help="skip the bf16 line's in-kernel clock measurement (thousands of launches of the "
+                   "diagnostic build: they would drown the product kernel in a profiler's per-kernel statistics)")
     args = p.parse_args(argv)
     kind, mlp, rays = CONFIGS[args.config]
     args.ray_kind = kind
     args.mlp = args.mlp or mlp
     args.mode = args.mode or ("render" if args.gpus == 1 else "both")
+    if args.ramp is None:
+        args.ramp = TIER_RAMP if (args.mlp in ("bf16", "x3") and args.mode == "render") else 0
     args.scaling = "strong" if args.global_rays else "weak"
     if args.global_rays:
         if args.global_rays % args.gpus:
@@ -367,9 +372,9 @@ def kernel_source_digest(mlp):
 
 def measured_traffic(args):
     """HBM bytes per launch of the fine-MLP kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (profiles/r02_hbm_traffic_<mlp>.json).  Only quoted when that profile was taken on THIS kernel source (digest recorded
+    (profiles/r03_hbm_traffic_<mlp>.json).  Only quoted when that profile was taken on THIS kernel source (digest recorded
     in the file) and at this launch size; otherwise null."""
-    tf = os.path.join(ROOT, "profiles", "r02_hbm_traffic_%s.json" % args.mlp)
+    tf = os.path.join(ROOT, "profiles", "r03_hbm_traffic_%s.json" % args.mlp)
     if not (os.path.exists(tf) and (args.rays, args.fine) == (4096, 128)):
         return None, None
     d = json.load(open(tf))
@@ -482,7 +487,7 @@ def main(argv=None):
             if args.mlp == "x3":
                 roof["issued_tflops"] = round(3 * ach, 2)
                 roof["frac_issued"] = round(3 * ach / PEAK["x3"], 4)
-            if args.mlp == "bf16" and (args.rays, args.fine) == (4096, 128):
+            if args.mlp == "bf16" and (args.rays, args.fine) == (4096, 128) and not args.no_clock:
                 roof["clock"] = bf16_in_kernel_clock(model.fine.flat_params().detach(), device)
         elif head == "train":
             roof = train_roofline(args, cfg, dt / args.steps)

@@ -62,17 +62,6 @@ __device__ __forceinline__ float g2_srcb(const float *__restrict__ P, const G2Sr
 
 __global__ __launch_bounds__(256) void mlp_bf16g2_pack_kernel(const float *__restrict__ P, G2Src pl, unsigned short *__restrict__ packed) {
     const int si = blockIdx.x;
-    if (si == G2_NSLICE) {  // (the chunk tails travel to LDS with their chunk and are never read: zero them once)
-        for (int i = threadIdx.x; i < G2_IMG_BYTES / 2; i += 256) {
-            bool inside = false;
-            for (int s = 0; s < G2_NSLICE && !inside; ++s) {
-                const int K = kG2K[kG2Slice[s][0]], lo = kG2Slice[s][2], hi = lo + 16 * g2_rowb(K) + 64;
-                inside = 2 * i >= lo && 2 * i < hi;
-            }
-            if (!inside) packed[i] = 0;
-        }
-        return;
-    }
     const int l = kG2Slice[si][0], K = kG2K[l], o0 = 16 * kG2Slice[si][1];
     unsigned short *dst = packed + kG2Slice[si][2] / 2;
     const int plane = 16 * g2_rowb(K);
@@ -99,7 +88,9 @@ DDN_EXPORT size_t ddnerf_mlp_bf16g2_packed_bytes(int depth_head) {
 DDN_EXPORT int ddnerf_mlp_bf16g2_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
     DDN_REQUIRE(params && packed, DDNERF_E_ARG);
     DDN_REQUIRE(ddn_aligned(packed, 16), DDNERF_E_ALIGN);
-    hipLaunchKernelGGL(mlp_bf16g2_pack_kernel, dim3(G2_NSLICE + 1), dim3(256), 0, (hipStream_t)stream, params, g2_make_src(depth_head),
+    // (the chunk tails travel to LDS with their chunk and are never read: zeroed once, so that the image is a function of the parameters)
+    if (hipMemsetAsync(packed, 0, (size_t)G2_IMG_BYTES, (hipStream_t)stream) != hipSuccess) return DDNERF_E_ARG;
+    hipLaunchKernelGGL(mlp_bf16g2_pack_kernel, dim3(G2_NSLICE), dim3(256), 0, (hipStream_t)stream, params, g2_make_src(depth_head),
                        (unsigned short *)packed);
     return ddn_launch_status();
 }

@@ -1,7 +1,7 @@
 """gpurun_out/refresh/* (scratch/refresh_profiles.sh) -> profiles/<round>_* (round: argv[1], default r02)"""
 import os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 O = os.path.join(R, "gpurun_out", "refresh")
 P = os.path.join(R, "profiles")
 pairs = [("bench_fp32.json", "render_fp32_bench.json"), ("bench_bf16.json", "render_bf16_bench.json"), ("bench_x3.json", "render_x3_bench.json"),

@@ -1,6 +1,6 @@
 """gpurun_out/pmc/* (scratch/pmc_all.sh) -> profiles/<round>_hbm_traffic_<mlp>.json, profiles/<round>_pmc_mfma.json (round: argv[1], default r02)"""
 import csv, collections, hashlib, json, os, re, sys
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "gpurun_out", "pmc")
 def short(n):
@@ -16,7 +16,7 @@ cal = {k: sum(v for v, _, _ in calib[k]["FETCH_SIZE"]) / len(calib[k]["FETCH_SIZ
 BF16_FACTOR = cal["calib_bf16rows"] / (524288 * 256 / 1024)   # raw FETCH_SIZE per true byte in the persistent bf16 kernel's row pattern
 TRUE_KB = 524288 * 512 / 1024
 mfma = {}
-for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512 + 16)), ("bf16", "void mlp_bf16_fwd_kernel<false>", 524288 * (256 + 16)),
+for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512 + 16)), ("bf16", "void mlp_bf16g2_fwd_kernel<false>", 524288 * (256 + 16)),
                         ("x3", "void mlp_x3_fwd16_kernel<false>", 524288 * (512 + 16))):
     f = agg(os.path.join(P, "fetch_" + mlp, "c_counter_collection.csv"))
     w = agg(os.path.join(P, "write_" + mlp, "c_counter_collection.csv"))
@@ -32,7 +32,7 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
     # factor measured on the same pattern in the same call.
     fetch_true_kb = fk["FETCH_SIZE_raw_KB"] / BF16_FACTOR if mlp == "bf16" else 2 * fk["FETCH_SIZE_raw_KB"]
     traffic = (fetch_true_kb + fk["WRITE_SIZE_KB"]) * 1024
-    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"], "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"]}[mlp]
+    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h"], "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"]}[mlp]
     digest = hashlib.md5()
     for f_ in srcs:
         digest.update(open(os.path.join(R, "ddnerf_amd", "csrc", f_), "rb").read())
@@ -48,8 +48,11 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
            "fetch_calibration": {"calib_stream_raw_over_true": round(cal["calib_stream"] / TRUE_KB, 4), "calib_rows_raw_over_true": round(cal["calib_rows"] / TRUE_KB, 4),
                                  "calib_bf16rows_raw_over_true": round(BF16_FACTOR, 4), "applied": "raw / calib_bf16rows" if mlp == "bf16" else "raw x 2"},
            "fine_mlp_%s_fwd_hbm_bytes_per_launch" % mlp: traffic, "algorithmic_bytes_per_launch": algo,
-           "why_above_algorithmic": ("the persistent bf16 kernel reads every feature row once and keeps it in registers; what is left above the algorithmic "
-                                     "bytes is the packed weight image (1.4 MB per XCD) and write granularity" if mlp == "bf16" else
+           "why_above_algorithmic": ("at this size the bf16 forward is the two-group kernel (mlp_bf16_g2.hip): it does not keep the encoded row in registers "
+                                     "(they hold a second group's activations instead) but fetches the 96 xyz columns again for the skip layer and the 32 "
+                                     "view-direction columns again for the dir layer, one or two passes ahead of their use: re-reads of rows this workgroup "
+                                     "fetched 50 us earlier, served by the L2 / MALL when they are still there and counted here when not; plus the packed weight "
+                                     "image (1.4 MB per XCD) and write granularity.  At the measured launch time the total is < 15 % of HBM bandwidth" if mlp == "bf16" else
                                      "by design the fp32 / x3 kernels re-read the 96 xyz feature columns for the skip layer instead of holding 48 registers "
                                      "across four layers (+201 MB if it misses L2), and 4096 workgroups each stream the whole weight image (2.6 MB) through L2; "
                                      "at the measured launch time this is < 2 % (fp32) / < 6 % (x3) of HBM bandwidth"),

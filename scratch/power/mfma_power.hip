@@ -30,7 +30,34 @@ __global__ __launch_bounds__(256, 1) void k(const bf16x8 *__restrict__ src, floa
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = lds[64 * i + lane];
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    if constexpr (MODE == 4) {
+    if constexpr (MODE == 5 || MODE == 6) {
+        constexpr int U = MODE == 6 ? UNR / 2 : 1;   // (the mix is ~1.9x the bytes per MFMA: UNR / 2 copies ~ the same 190 KB)
+        f32x4 acc[8] = {};
+        unsigned d0 = tid, d1 = tid * 3, d2 = tid * 5, d3 = tid * 7;
+        for (int it = 0; it < iters / U; ++it) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    bf16x8 av = a[s & 3];
+                    a[(s + 2) & 3] = lds[((u * 16 + s) & 63) * 64 + lane];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[4 * (s & 1) + c]) : "v"(av), "v"(b[(c + s) & 7]));
+                        if (c == 1) asm volatile("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0" : "+v"(d0), "+v"(d1));
+                        if (c == 2) asm volatile("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0" : "+v"(d2), "+v"(d3));
+                        if (c == 3) asm volatile("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0" : "+v"(d0), "+v"(d2));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        f32x4 s = {};
+        asm volatile("s_nop 7\n\ts_nop 7");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += acc[i];
+        out[(size_t)blockIdx.x * 256 + tid] = s[0] + s[1] + s[2] + s[3] + (float)(d0 + d1 + d2 + d3);
+    } else if constexpr (MODE == 4) {
         f32x4 acc[8] = {};
         for (int it = 0; it < iters / UNR; ++it) {
 #pragma unroll
@@ -143,6 +170,8 @@ int main(int argc, char **argv) {
     printf("data: %s, %d CUs\n", zero == 0 ? "uniform(-1,1)" : zero == 1 ? "zeros" : zero == 2 ? "uniform*1e-3" : "half zeros", ncu);
     run<0>("16x16x32 registers", src, out, stamps, ncu, iters);
     run<4>("16x16x32 registers, straight-line 196 KB", src, out, stamps, ncu, iters / UNR * UNR);
+    run<5>("kernel-like mix (LDS A + 6 VALU / k-step), rolled", src, out, stamps, ncu, iters / UNR * UNR);
+    run<6>("kernel-like mix, straight-line ~190 KB", src, out, stamps, ncu, iters / UNR * UNR);
     run<1>("16x16x32 A from LDS (1 ds_read_b128 / 4 MFMA)", src, out, stamps, ncu, iters);
     run<2>("32x32x16 registers", src, out, stamps, ncu, iters);
     run<3>("32x32x16 A from LDS (1 ds_read_b128 / 2 MFMA)", src, out, stamps, ncu, iters);
