@@ -226,7 +226,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 }
 
 #ifndef ENC_SPB
-#define ENC_SPB 16  // samples per 256-thread block
+#define ENC_SPB 32  // samples per 256-thread block (measured on the bf16 rows, fine / coarse pass: 16 -> 54 / 32 us, 32 -> 48 / 26, 64 -> 53 / 30)
 #endif
 
 template <bool BF16>
@@ -234,7 +234,10 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
                                                      void *__restrict__ feat_, int n, int S, int cylinder) {
     __shared__ float g_mean[ENC_SPB][4];
     __shared__ float g_cov[ENC_SPB][4];
-    __shared__ float row[ENC_SPB][DDNERF_FEAT_LD];
+    __shared__ __attribute__((aligned(16))) float row[ENC_SPB][100];   // the IPE columns of the block's samples (stride 100: the 16
+                                                                       // samples of one column sit in 16 different banks)
+    __shared__ __attribute__((aligned(16))) float dirv[ENC_SPB][32];   // columns 96..127 of the block's RAYS (a ray's samples share them)
+    __shared__ int ray_of[ENC_SPB];                                    // sample -> its ray's row of dirv
     const size_t M = (size_t)n * S;
     const size_t m0 = (size_t)blockIdx.x * ENC_SPB;
     const int tid = threadIdx.x;
@@ -254,54 +257,70 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
             float dmag = fmaxf(1e-10f, (q0 + q1) + q2);                       // :38
             float da = r[3 + a], qa = da * da;
             float nul = 1.0f - qa / dmag;                                     // :42
+            if (a == 0) ray_of[ls] = i - (int)(m0 / S);
             g_mean[ls][a] = da * tm + r[a];                                   // :36, :30
             g_cov[ls][a] = tv * qa + rv * nul;                                // :43-45
         }
     }
-    // phase 1b: view-direction encoding: 27 values per sample (same for a ray's samples); walked from the far end of the
-    // block so that it lands on other waves than phase 1
+    // phase 1b: view-direction encoding: 27 values per RAY (the same for all of a ray's samples: a block of 16 consecutive samples
+    // touches one ray when S is a multiple of 16, at most 16); walked from the far end of the block so that it lands on other waves
+    // than phase 1
+    const int ray0 = (int)(m0 / S);
     {
-        for (int t2 = 255 - tid; t2 < ENC_SPB * 12; t2 += 256) {
-            int ls = t2 / 12, k = t2 % 12;  // k: 0..11 -> (freq f = k/3, axis a = k%3), emits sin and cos
-            size_t m = m0 + ls;
-            if (m < M) {
-                int i = (int)(m / S);
-                int f = k / 3, a = k % 3;
-                float v = rays[12 * (size_t)i + 9 + a];
-                float x = v * (float)(1 << f);                                // nerf_helpers.py:163-165
-                row[ls][96 + 3 + f * 6 + a] = BF16 ? fast_sin(x) : enc_sin(x);                       // |x| <= 8
-                row[ls][96 + 3 + f * 6 + 3 + a] = BF16 ? fast_sin(x + 1.57079637f) : enc_sin(x, 1);  // cos
-                if (f == 0) row[ls][96 + a] = v;                              // include_input
-                if (k < 5) row[ls][123 + k] = 0.0f;                           // pad columns
-            }
+        const size_t mlast = (m0 + ENC_SPB < M ? m0 + ENC_SPB : M) - 1;
+        const int nrays = (int)(mlast / S) - ray0 + 1;
+        for (int t2 = 255 - tid; t2 < nrays * 12; t2 += 256) {
+            int lr = t2 / 12, k = t2 % 12;  // k: 0..11 -> (freq f = k/3, axis a = k%3), emits sin and cos
+            int f = k / 3, a = k % 3;
+            float v = rays[12 * (size_t)(ray0 + lr) + 9 + a];
+            float x = v * (float)(1 << f);                                // nerf_helpers.py:163-165
+            dirv[lr][3 + f * 6 + a] = BF16 ? fast_sin(x) : enc_sin(x);                       // |x| <= 8
+            dirv[lr][3 + f * 6 + 3 + a] = BF16 ? fast_sin(x + 1.57079637f) : enc_sin(x, 1);  // cos
+            if (f == 0) dirv[lr][a] = v;                                  // include_input
+            if (k < 5) dirv[lr][27 + k] = 0.0f;                           // pad columns
         }
     }
     __syncthreads();
-    // phase 2: IPE, 3 threads-rounds of 256: thread -> (sample ls, pair p in 0..47)
+    // phase 2: IPE, 3 thread-rounds of 256: thread -> (pair p in 0..47, sample ls); the sample is the FAST index, so a wave covers
+    // four pairs = at most two octaves, and the octaves whose arguments stay below 100 pi (the low ones) skip safe_sin's remainder
+    // as a wave
     for (int e = tid; e < ENC_SPB * 48; e += 256) {
-        int ls = e / 48, p = e % 48;
-        if (m0 + ls < M) {
-            int l = p / 3, a = p % 3;
-            float s = (float)(1 << l);
-            float y = g_mean[ls][a] * s;                                      // :130
-            float yv = g_cov[ls][a] * (s * s);                                // :131
-            float damp = BF16 ? fast_exp_neg(-0.5f * yv) : enc_exp_neg(-0.5f * yv);   // :149  (yv >= 0)
-            row[ls][p] = damp * safe_sin_t<BF16>(y);
-            row[ls][48 + p] = damp * safe_sin_t<BF16>(y + 1.57079637f);               // :143  y + 0.5*fp32(pi)
+        int p = e / ENC_SPB, ls = e % ENC_SPB;
+        int l = p / 3, a = p % 3;
+        float s = (float)(1 << l);
+        const bool live = m0 + ls < M;
+        float y = live ? g_mean[ls][a] * s : 0.0f;                            // :130
+        float yv = live ? g_cov[ls][a] * (s * s) : 0.0f;                      // :131
+        float damp = BF16 ? fast_exp_neg(-0.5f * yv) : enc_exp_neg(-0.5f * yv);   // :149  (yv >= 0)
+        float ys = y, yc = y + 1.57079637f;                                   // :143  y + 0.5*fp32(pi)
+        const float T = 314.159271f;                                          // 100 * fp32(pi), general_utils/math_utils.py:155
+        if (__builtin_amdgcn_ballot_w64(!(fabsf(ys) < T) || !(fabsf(yc) < T)) != 0) {
+            ys = (fabsf(ys) < T) ? ys : remainder_pos(ys, T);
+            yc = (fabsf(yc) < T) ? yc : remainder_pos(yc, T);
+        }
+        if (live) {
+            row[ls][p] = damp * (BF16 ? fast_sin(ys) : enc_sin(ys));
+            row[ls][48 + p] = damp * (BF16 ? fast_sin(yc) : enc_sin(yc));
         }
     }
     __syncthreads();
     // phase 3: coalesced row stores (16 rows x 128 columns)
     if (BF16) {
-        unsigned short *feat = (unsigned short *)feat_;
-        for (int e = tid; e < ENC_SPB * DDNERF_FEAT_LD / 2; e += 256) {
-            int ls = e / (DDNERF_FEAT_LD / 2), c = (e % (DDNERF_FEAT_LD / 2)) * 2;
+        // bf16 rows are stored in the MFMA k-order of the 16x16x32 MLP kernel (mlp_bf16_common.h korder32): inside every 32 columns,
+        // position 8g + e holds column 16(e>>2) + 4g + (e&3).  A thread owns positions 8g .. 8g+7 of one 32-column group: columns
+        // 4g .. 4g+3 and 16 + 4g .. +3, i.e. two aligned float4 reads from the LDS row and ONE 16-byte store (16 per row).
+        char *feat = (char *)feat_;
+        for (int e = tid; e < ENC_SPB * (DDNERF_FEAT_LD / 8); e += 256) {
+            const int ls = e / (DDNERF_FEAT_LD / 8), j = e % (DDNERF_FEAT_LD / 8), grp = j >> 2, g = j & 3;
             if (m0 + ls < M) {
-                // bf16 rows are stored in the MFMA k-order of the 16x16x32 MLP kernel (mlp_bf16_common.h korder32):
-                // inside every 32 columns, position 8g + e holds column 16(e>>2) + 4g + (e&3)
-                const int cs = (c & ~31) | (16 * ((c >> 2) & 1) + 4 * ((c >> 3) & 3) + (c & 3));
-                unsigned v = (unsigned)f32_to_bf16(row[ls][cs]) | ((unsigned)f32_to_bf16(row[ls][cs + 1]) << 16);
-                *(unsigned *)(feat + (m0 + ls) * DDNERF_FEAT_LD + c) = v;
+                const float *src = grp < 3 ? &row[ls][32 * grp] : &dirv[ray_of[ls]][0];
+                const float4 a = *(const float4 *)(src + 4 * g), b = *(const float4 *)(src + 16 + 4 * g);
+                uint4 v;
+                v.x = (unsigned)f32_to_bf16(a.x) | ((unsigned)f32_to_bf16(a.y) << 16);
+                v.y = (unsigned)f32_to_bf16(a.z) | ((unsigned)f32_to_bf16(a.w) << 16);
+                v.z = (unsigned)f32_to_bf16(b.x) | ((unsigned)f32_to_bf16(b.y) << 16);
+                v.w = (unsigned)f32_to_bf16(b.z) | ((unsigned)f32_to_bf16(b.w) << 16);
+                *(uint4 *)(feat + ((m0 + ls) * DDNERF_FEAT_LD + 8 * j) * 2) = v;
             }
         }
     } else {
@@ -309,7 +328,8 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
         for (int e = tid; e < ENC_SPB * DDNERF_FEAT_LD / 4; e += 256) {
             int ls = e / (DDNERF_FEAT_LD / 4), c = (e % (DDNERF_FEAT_LD / 4)) * 4;
             if (m0 + ls < M) {
-                float4 v = make_float4(row[ls][c], row[ls][c + 1], row[ls][c + 2], row[ls][c + 3]);
+                const float *src = c < 96 ? &row[ls][c] : &dirv[ray_of[ls]][c - 96];
+                float4 v = *(const float4 *)src;
                 *(float4 *)(feat + (m0 + ls) * DDNERF_FEAT_LD + c) = v;
             }
         }
