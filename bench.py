@@ -199,16 +199,20 @@ def build_model(args, device, mlp=None):
 
 
 class KernelTimer:
-    """HIP-event timing of one kernel family on torch's current stream (the stream the C ABI launches on)."""
+    """HIP-event timing of the dominant kernel (the MLP launch of `only` samples: the fine pass) on torch's current stream (the stream
+    the C ABI launches on).  An event record is a barrier packet of its own: ~6 us of idle GPU in front of and behind the launch it
+    brackets (rocprofv3 kernel trace), so only the launches that are reported carry one -- timing the coarse launch too cost the
+    0.75-ms bf16 step another 12 us."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.pairs = []
         self.active = False
+        self.only = only
 
     def __call__(self, M, launch):
         import torch
 
-        if not self.active:
+        if not self.active or (self.only is not None and M != self.only):
             return launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -426,7 +430,7 @@ def main(argv=None):
     ro, rd, rad, tgt = (torch.from_numpy(x).to(device) for x in synthetic.make_rays(args.ray_kind, args.rays, 1 + rank))
     torch.manual_seed(1234 + rank)
 
-    timer = KernelTimer()
+    timer = KernelTimer(only=args.rays * args.fine)
     ops.MLP_LAUNCH_HOOK = timer
 
     def fence():

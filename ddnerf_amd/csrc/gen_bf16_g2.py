@@ -34,7 +34,11 @@ K = [96, 256, 256, 256, 256, 352, 256, 256, 256, 288, 128]      # packed layers 
 SLOT_BYTES = 36 * 1024
 NSLOT = 4
 DEPTH = 4        # A fragments are read this many k-steps ahead
-STAMP_BLOCKS = (8, 20)   # (diagnostic builds: the periods whose blocks get a stamp of their own, behind the period stamps)
+# Diagnostic (-DBF16_STAMP) builds: the C++ shell stamps the tile loop of every workgroup (in-kernel clock, cycles per tile: what
+# bench.py reports).  G2_STAMP_PERIODS=1 in the generator's environment adds a stamp at the end of every period, and per block inside
+# the window STAMP_BLOCKS (scratch/g2_clock.py reads them); each costs a scalar-memory round trip, so they are off by default.
+STAMP_PERIODS = os.environ.get("G2_STAMP_PERIODS", "0") == "1"
+STAMP_BLOCKS = (8, 20)
 DMA_SPAN_NUM, DMA_SPAN_DEN = [int(x) for x in os.environ.get("G2_DMA_SPAN", "1/1").split("/")]   # the part of its issue period over which a chunk's LDS-DMA pieces are spread
 FEAT_ROW = 256   # bytes of one encoded sample (DDNERF_FEAT_LD bf16)
 TILE = 512
@@ -279,7 +283,7 @@ class Gen:
         self.vm_issue("dma")
 
     def stamp_pass(self, p):
-        if not self.stamp:
+        if not (self.stamp and STAMP_PERIODS):
             return
         self.e("s_memtime s[%d:%d]" % (S_TIME, S_TIME + 1))
         self.lg_flush()
@@ -605,7 +609,7 @@ class Gen:
         e("s_lshl_b32 s%d, %%5, 7" % S_T0)
         e("s_add_u32 s%d, s%d, s%d" % (S_RB, S_RB, S_T0))
         e("s_mul_i32 s%d, s%d, %d" % (S_RB, S_RB, self.rs))
-        if self.stamp:
+        if self.stamp and STAMP_PERIODS:
             e("s_cmp_eq_u32 %5, 0")
             e("s_cselect_b64 s[%d:%d], 1, 0" % (S_SEXEC, S_SEXEC + 1))
         e("s_cmp_lg_u32 %6, %8")

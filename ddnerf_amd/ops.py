@@ -217,24 +217,29 @@ def dd_records_launch(weights, mus, sigmas, ssig):
     n, nc = weights.shape
     dev = weights.device
     outs = [torch.empty(n * nc, dtype=torch.float32, device=dev) for _ in range(3)]
-    total = torch.empty(1, dtype=torch.int32, device=dev)
+    total = _records_slot(dev)
     ws = torch.empty(_lib.lib().ddnerf_dd_records_workspace_bytes(n, nc), dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().ddnerf_dd_records(_ptr(weights), _ptr(mus), _ptr(sigmas), _ptr(ssig), n, nc, *[_ptr(o) for o in outs],
                                             _ptr(total), _ptr(ws), _stream()), "ddnerf_dd_records")
-    return _records_ticket(outs, total, dev)
+    return _records_ticket(outs, total)
 
 
-def _records_ticket(outs, total, dev):
-    """the asynchronous copy of the records' length into pinned memory + the event dd_records_finish waits for"""
+def _records_slot(dev):
+    """where the compaction kernel writes the records' length: one int32 of PINNED host memory (the device writes it in place --
+    pinned memory is mapped into the device's address space -- so no copy is enqueued behind the kernel)"""
     ring = _PINNED.get(str(dev))
     if ring is None:  # (built once per device: a setdefault(...) default would allocate eight pinned tensors on every chunk)
         ring = _PINNED[str(dev)] = {"slots": [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(8)], "next": 0}
     host = ring["slots"][ring["next"] % 8]
     ring["next"] += 1
-    host.copy_(total, non_blocking=True)
+    return host
+
+
+def _records_ticket(outs, host):
+    """the event dd_records_finish waits for, recorded right behind the compaction"""
     ev = torch.cuda.Event()
     ev.record()
-    return outs, host, ev, total
+    return outs, host, ev, host
 
 
 def dd_records_finish(ticket):
@@ -294,7 +299,7 @@ def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, b
     head["scal"] = e(4)
     c = dict(rgb_map=e(n, 3), disp=e(n), acc=e(n), weights=e(n, nc), depth=e(n), cdisp=e(n), rgb=None)
     outs = [e(n * nc) for _ in range(3)]
-    total = torch.empty(1, dtype=torch.int32, device=dev)
+    total = _records_slot(dev)
     ws = torch.empty(_lib.lib().ddnerf_dd_coarse_workspace_bytes(n, nc), dtype=torch.uint8, device=dev)
     flags = (1 if white_bkgd else 0) | (2 if blender else 0)
     _lib.check(_lib.lib().ddnerf_dd_coarse_forward(
@@ -302,7 +307,7 @@ def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, b
         *[_ptr(head[k]) for k in ("mus", "sigmas", "left", "part", "ssig", "sleft", "spart", "scal")],
         *[_ptr(c[k]) for k in ("rgb_map", "disp", "acc", "weights", "depth", "cdisp")], *[_ptr(o) for o in outs], _ptr(total), _ptr(ws),
         _stream()), "ddnerf_dd_coarse_forward")
-    return c, head, _records_ticket(outs, total, dev)
+    return c, head, _records_ticket(outs, total)
 
 
 def composite_forward_keep(raw, t_vals, rays, noise, mus, white_bkgd, blender, dp_filter):

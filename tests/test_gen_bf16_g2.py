@@ -27,7 +27,9 @@ def gen():
 
 @pytest.fixture(scope="module", params=[(0, 0), (1, 0), (0, 1)], ids=["rgb", "depth_head", "stamped"])
 def body(gen, request):
+    gen.STAMP_PERIODS = bool(request.param[1])       # (the per-period stamps of the diagnostic build: opt-in in the generator)
     g, blocks, nk = gen.generate(*request.param)     # (asserts that the counters' steady state is a fixed point)
+    gen.STAMP_PERIODS = False
     return [x.strip() for x in g.out if x.strip() and not x.startswith(";")], request.param
 
 
