@@ -334,7 +334,7 @@ def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
     L.ddnerf_debug_set_stamps_g2.argtypes = [V]
     n_cu = torch.cuda.get_device_properties(device).multi_processor_count
     stamps = {"g1": torch.zeros(n_cu * 6, dtype=torch.int64, device=device),
-              "g2": torch.zeros(n_cu * (6 + 160), dtype=torch.int64, device=device)}   # (+ the two-group build's per-period stamps)
+              "g2": torch.zeros(n_cu * (6 + 192), dtype=torch.int64, device=device)}   # (+ the two-group build's per-period stamps)
     if (L.ddnerf_mlp_bf16_pack(flat_params.data_ptr(), 0, packed.data_ptr(), st) or L.ddnerf_debug_set_stamps(stamps["g1"].data_ptr())
             or L.ddnerf_debug_set_stamps_g2(stamps["g2"].data_ptr())):
         return None

@@ -39,6 +39,7 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 # the window STAMP_BLOCKS (scratch/g2_clock.py reads them); each costs a scalar-memory round trip, so they are off by default.
 STAMP_PERIODS = os.environ.get("G2_STAMP_PERIODS", "0") == "1"
 STAMP_BLOCKS = (8, 20)
+STAMP_KSTEPS = [tuple(int(v) for v in x.split(":")) for x in os.environ.get("G2_STAMP_KSTEPS", "").split(",") if x]   # (period, block in period): a stamp per k-step
 DMA_SPAN_NUM, DMA_SPAN_DEN = [int(x) for x in os.environ.get("G2_DMA_SPAN", "1/1").split("/")]   # the part of its issue period over which a chunk's LDS-DMA pieces are spread
 FEAT_ROW = 256   # bytes of one encoded sample (DDNERF_FEAT_LD bf16)
 TILE = 512
@@ -187,6 +188,7 @@ class Gen:
         self.vm = list(carry["vm"]) if carry else []        # outstanding vector-memory loads: (serial, "dma" | "x")
         self.vm_serial = carry["serial"] if carry else 0
         self.pending = dict(carry["pending"]) if carry else {}   # register key -> serial of the load that fills it
+        self.last_piece = dict(carry["last_piece"]) if carry else {}   # chunk load (index in `real`) -> serial of its last LDS-DMA piece
         self.lg = []                                        # outstanding LDS reads (keys)
         self.nmfma = 0
 
@@ -278,9 +280,11 @@ class Gen:
         self.e("s_add_u32 s%d, s%d, %d" % (S_T1, S_T0, lds))
         self.e("s_add_u32 m0, s%d, %%4" % S_T1)
 
-    def dma_piece(self, imm):
+    def dma_piece(self, imm, key=None, last=False):
         self.e("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d" % (V_LANE16, S_CUR, S_CUR + 1, imm))
-        self.vm_issue("dma")
+        serial = self.vm_issue("dma")
+        if last:
+            self.last_piece[key] = serial
 
     def stamp_pass(self, p):
         if not (self.stamp and STAMP_PERIODS):
@@ -419,12 +423,14 @@ class Gen:
             x((1, 0), treg(b, 0), 0, 0, b, 3, ("T", b, 0))
         if lk == 9 and g == 0 and l == 9 and b < 4:   # view directions of group 1: fragment 4 of F0 (layer 9 writes fragments 0-3 only)
             x((1, 0), frag(0, b, 4), 0, 1, b, 3, ("F", 0, b, 4))
-        if lk == 9 and g == 1 and l == 9 and b < 6:   # the next tile's layer-0 input of group 0 -> F1[c][4..6], two fragments per block
-            for j in range(2):
-                c, q = divmod(2 * b + j, 3)
-                x((2 + j, 0), frag(1, c, 4 + q), 1, 0, c, q, ("F", 1, c, 4 + q))
-        if lk == 9 and g == 1 and l == 9 and b < 4:
-            x((1, 0), treg(b, 0), 1, 1, b, 0, ("T", b, 0))
+        # the next tile's layer-0 input of group 0 -> F1[c][4..6], as early in the last pass as F1 is free (loads retire in order: one
+        # issued late in the tile would wait behind the LDS-DMA pieces of the next tile's first chunks, 2.5 - 3 k cycles each)
+        if lk == 9 and g == 1 and l == 9 and b < 3:
+            for j in range(4):
+                c, q = divmod(4 * b + j, 3)
+                x((1 + j, 0), frag(1, c, 4 + q), 1, 0, c, q, ("F", 1, c, 4 + q))
+        if lk == 9 and g == 1 and l == 9 and 3 <= b < 7:
+            x((1, 0), treg(b - 3, 0), 1, 1, b - 3, 0, ("T", b - 3, 0))
         return ev
 
     def tile(self):
@@ -437,19 +443,43 @@ class Gen:
             per_ksteps[blocks[i]["period"]].append(n)
         # DMA pieces: the instance issued in a period, spread evenly over the period's k-steps
         dma_at = defaultdict(list)
+        # (the chunk whose turn is the one-block period that ends pass (5, g0) is issued a period later, behind group 1's xyz loads of
+        # that block: loads retire in order, and behind nine fresh LDS-DMA pieces those loads cost group 1's first block ~2 k cycles)
+        e2_period = next(x["period"] for x in blocks if x["lk"] == 5 and x["g"] == 0 and x["b"] == 15)
+        eff_issue = {}
         for per in range(NPER):
             for d in ISSUE_IN.get(per, []):
                 npw = npw_of(d["chunk"])
-                ks_list = per_ksteps[per]
+                shifted = per == e2_period
+                eff_issue[id(d)] = per + 1 if shifted else per
+                # (a group of pieces shares M0 and the source base with its setup: two chunks' pieces must not interleave, so the period
+                # that takes the shifted chunk is split -- first half the shifted one, second half its own)
+                if shifted:
+                    ks_list = per_ksteps[per + 1][2:len(per_ksteps[per + 1]) // 2]
+                elif per == e2_period + 1:
+                    ks_list = per_ksteps[per][len(per_ksteps[per]) // 2:]
+                else:
+                    ks_list = per_ksteps[per]
                 # (measured, bf16 fine pass: spread over the whole period 0.6726 of peak, over 3/4 0.6704, 1/2 0.6686, 1/3 0.6678 -- the
                 # workgroups of a launch run in step, so a denser issue is a burst on the L2 of every XCD)
                 span = len(ks_list) * DMA_SPAN_NUM // DMA_SPAN_DEN
                 for i in range(npw):
                     dma_at[ks_list[(i * span) // npw]].append((d, i, npw))
 
-        # A chunk whose load was issued only two periods before its first use is certified by the barrier right in front of that use:
-        # nothing of it is read ahead across that barrier (the reads wait in `deferred` and follow the barrier)
-        late = {d["uses"][0] for d in real if d["uses"][0] - d["issue"] < 3}
+        # When must a chunk have landed (for every wave: a wait for this wave's pieces, then a barrier)?  Its first fragments are read
+        # AHEAD, in the last k-steps of the period before its first use q: by the barrier that ends period q - 2.  A chunk that this
+        # would give too little time -- issued only two periods before q, or followed by a short period (an LDS-DMA piece takes 2.5 - 3 k
+        # cycles to land when every CU streams; the one-block periods that end the skip layer's passes are 700) -- is "late": nothing of
+        # it is read ahead (the reads wait in `deferred` and follow the barrier that ends period q - 1, which certifies it).
+        # The wait at the end of a period is for exactly the chunks due there, not for everything issued so far.
+        late, due = set(), defaultdict(list)
+        for key, d in enumerate(real):
+            eff = eff_issue[id(d)] if d["issue"] >= 0 else d["issue"]
+            is_late = d["uses"][0] - eff < 3 or len(per_ksteps[(eff + 1) % NPER]) < 20
+            if is_late:
+                late.add(d["uses"][0])
+            due[(d["uses"][0] - (1 if is_late else 2)) % NPER].append(key)
+            assert (d["uses"][0] - (1 if is_late else 2)) >= eff, ("a chunk due before it is issued", key)
         state = dict(period=0, deferred=[])
 
         def rd_a(n, now=False):
@@ -512,11 +542,14 @@ class Gen:
                     if pi_ % 8 == 0:
                         c0 = centre(pi_, npw)
                         gaps[(u, j)].append(("dma_setup", IMG_OFF[d["chunk"]] + c0 * 1024, d["slot"] * SLOT_BYTES + c0 * 1024, npw))
-                    gaps[(u, j + 1)].append(("dma", (pi_ - centre(pi_, npw)) * 1024))
+                    gaps[(u, j + 1)].append(("dma", (pi_ - centre(pi_, npw)) * 1024, real.index(d), pi_ == npw - 1))
             for it in self.x_events(blk):
                 gaps[it[0]].append(it[1:])
+            kst = (blk["period"], [x for x in blocks if x["period"] == blk["period"]].index(blk))
             for u, ks in enumerate(order):
                 n = K0 + u
+                if STAMP_PERIODS and kst in STAMP_KSTEPS:
+                    self.stamp_pass(130 + 12 * STAMP_KSTEPS.index(kst) + u)
                 for mi in range(4):
                     c = mi
                     kind, r, key = self.bsrc(blk, ks, c)
@@ -539,7 +572,7 @@ class Gen:
                         elif it[0] == "dma_setup":
                             self.dma_setup(*it[1:])
                         elif it[0] == "dma":
-                            self.dma_piece(it[1])
+                            self.dma_piece(*it[1:])
                         elif it[0] == "x":
                             self.x_load(*it[1:])
                         elif it[0] == "pf":
@@ -549,8 +582,9 @@ class Gen:
                         elif it[0] == "base_h":
                             self.set_base_h(*it[1:])
             if blk["last"]:
-                # everything issued before this period began has landed once the loads of this period are all that is left
-                self.vm_wait_serial(period_mark, "dma")
+                serials = [self.last_piece[k] for k in due.get(blk["period"], []) if k in self.last_piece]
+                if serials:
+                    self.vm_wait_serial(max(serials))
                 self.e("s_barrier")
                 state["period"] = blk["period"] + 1
                 for kind_, x in state["deferred"]:
@@ -621,11 +655,11 @@ class Gen:
 def generate(depth_head, stamp):
     g1 = Gen(depth_head, stamp)
     g1.tile()                                                  # pass 1: what a tile leaves outstanding for the next one
-    carry = dict(vm=g1.vm, serial=g1.vm_serial, pending=g1.pending)
+    carry = dict(vm=g1.vm, serial=g1.vm_serial, pending=g1.pending, last_piece=g1.last_piece)
     g2 = Gen(depth_head, stamp, carry)
     g2.head()
     blocks, NK = g2.tile()
-    g3 = Gen(depth_head, stamp, dict(vm=g2.vm, serial=g2.vm_serial, pending=g2.pending))   # (fixed point: pass 3 must repeat pass 2)
+    g3 = Gen(depth_head, stamp, dict(vm=g2.vm, serial=g2.vm_serial, pending=g2.pending, last_piece=g2.last_piece))   # (fixed point: pass 3 must repeat pass 2)
     g3.head()
     g3.tile()
     strip = lambda out: [x for x in out]

@@ -97,7 +97,7 @@ DDN_EXPORT int ddnerf_mlp_bf16g2_pack(const float *params, int depth_head, void 
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------------------
 #ifdef BF16_STAMP  // diagnostic build only: in-kernel clock, cycles per tile (six values per workgroup), the clock at the end of every
-                   // period of the workgroup's last tile (96 values per workgroup behind those: slot 0 tile begin, slot p + 1 the end of period p)
+                   // period of the workgroup's last tile (192 values per workgroup behind those: slot 0 tile begin, slot p + 1 the end of period p, then the generator's optional per-block / per-k-step stamps)
 __device__ unsigned long long *g_bf16g2_stamps;
 DDN_EXPORT int ddnerf_debug_set_stamps_g2(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bf16g2_stamps), &p, sizeof(p)); }
 #define G2_BODY_D0 "mlp_bf16_g2_body_d0s.gen.inc"
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2_fwd_kernel(const char *__re
     const unsigned plo = (unsigned)(size_t)packed, phi = (unsigned)((size_t)packed >> 32);
     const unsigned grid = gridDim.x, tile0 = blockIdx.x;
 #ifdef BF16_STAMP
-    unsigned long long *const wg_stamps = g_bf16g2_stamps ? g_bf16g2_stamps + 6 * 256 + 160 * blockIdx.x : nullptr;
+    unsigned long long *const wg_stamps = g_bf16g2_stamps ? g_bf16g2_stamps + 6 * 256 + 192 * blockIdx.x : nullptr;
     const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned done = 0;

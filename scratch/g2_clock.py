@@ -17,7 +17,7 @@ packed = torch.empty(L.ddnerf_mlp_bf16g2_packed_bytes(0), dtype=torch.uint8, dev
 L.ddnerf_mlp_bf16g2_pack.argtypes = [V, C.c_int, V, V]
 assert L.ddnerf_mlp_bf16g2_pack(flat.data_ptr(), 0, packed.data_ptr(), st) == 0
 f = L.ddnerf_mlp_bf16g2_forward; f.argtypes = [V, V, C.c_int, V, C.c_long, V]
-stamps = torch.zeros(256 * 6 + 256 * 160, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(256 * 6 + 256 * 192, dtype=torch.int64, device="cuda")
 L.ddnerf_debug_set_stamps_g2.argtypes = [V]
 assert L.ddnerf_debug_set_stamps_g2(stamps.data_ptr()) == 0
 t0 = time.time(); n = 0
@@ -41,7 +41,7 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("gen", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ddnerf_amd", "csrc", "gen_bf16_g2.py"))
 sys.argv = ["gen"]
 gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
-allp = allst[256 * 6:].reshape(256, 160).astype(np.float64)
+allp = allst[256 * 6:].reshape(256, 192).astype(np.float64)
 ps = allp[:, :gen.NPER + 1]
 d = np.diff(ps, axis=1)
 med = np.median(d, axis=0)
@@ -65,3 +65,8 @@ for p_ in range(lo, hi):
     dd = np.median(np.diff(t, axis=1), axis=0)
     print("period %2d %s: blocks %s | barrier+tail %4.0f" % (p_, gen.PASSES[gen.PERIODS[p_][0]], " ".join("%5.0f" % x for x in dd[:-1]), dd[-1]))
     j += nb
+
+ks = [tuple(int(v) for v in x.split(":")) for x in os.environ.get("G2_STAMP_KSTEPS", "").split(",") if x]
+for i, (per, b) in enumerate(ks):
+    t = allp[:, 130 + 12 * i:130 + 12 * i + 11]
+    print("period %d block %d: cycles between k-step stamps: %s" % (per, b, " ".join("%5.0f" % x for x in np.median(np.diff(t, axis=1), axis=0))))

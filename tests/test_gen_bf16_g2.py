@@ -172,6 +172,7 @@ def test_weight_stream_replay(gen, body):
         if t.startswith("s_") and " " in t and not t.startswith(("s_cmp", "s_cbranch", "s_cselect")):
             salu(t)
     base_slot, flight, barrier_no = {}, [], 0
+    fills = {}
     uncertified = {s: [] for s in range(gen.NSLOT)}      # slot -> [retired?] flags of pieces not yet followed by a barrier
     last_read = {s: -1 for s in range(gen.NSLOT)}        # slot -> barrier count at its last read
     nread = 0
@@ -195,6 +196,12 @@ def test_weight_stream_replay(gen, body):
                 slot, rem = divmod(sg["m0"] + off, S)
                 assert 0 <= slot < gen.NSLOT and rem + 1024 <= S, t
                 assert last_read[slot] < barrier_no, ("LDS-DMA into a slot that was read since the last barrier", t)
+                # source and destination belong together: (image offset of the piece) - (its offset in the slot) is the image offset
+                # of ONE chunk for every piece of a fill, and this wave's pieces tile its share of the chunk exactly once
+                assert sg.get("s84") is not None, t
+                chunk_off = (sg["s84"] + off) - rem
+                assert chunk_off in gen.IMG_OFF, ("a piece whose source and destination belong to different chunks", t)
+                fills.setdefault((slot, chunk_off, barrier_no // 10**9), []).append(rem)
                 p = {"retired": False}
                 flight.append(p)
                 uncertified[slot].append(p)
@@ -218,3 +225,9 @@ def test_weight_stream_replay(gen, body):
             elif op.startswith("s_") and " " in t and not op.startswith(("s_cmp", "s_cbranch", "s_cselect", "s_nop", "s_memtime", "s_mov_b64")):
                 salu(t)
     assert nread == 3 * (2410 + 308)                      # one A fragment per k-step, one bias tile per block
+    for (slot, chunk_off, _), rems in fills.items():
+        ci = gen.IMG_OFF.index(chunk_off)
+        npw = gen.npw_of(ci)
+        per_tile = sorted(rems)
+        want = sorted([(3 * npw + i) * 1024 for i in range(npw)] * (len(rems) // npw))   # (the replay is wave 3: %5 = 3)
+        assert len(rems) % npw == 0 and per_tile == want, ("a chunk's pieces do not tile this wave's share", slot, ci)
