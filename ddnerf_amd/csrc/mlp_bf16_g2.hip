@@ -207,13 +207,24 @@ extern "C" size_t ddnerf_mlp_bf16g1_packed_bytes(int depth_head);
 extern "C" int ddnerf_mlp_bf16g1_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 extern "C" int ddnerf_mlp_bf16g1_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
 static size_t g2_image_offset(int depth_head) { return (ddnerf_mlp_bf16g1_packed_bytes(depth_head) + 255) & ~(size_t)255; }
-static long g2_min_samples() {  // DDNERF_BF16_G2_MIN: launches of at least this many samples run the two-group kernel (0: all, -1: none)
-    static long v = -2;
-    if (v == -2) {
+// Which kernel?  Both are persistent (one workgroup per CU walks the tiles), so a launch takes ceil(tiles / CUs) rounds of one tile
+// time; a 512-sample tile of the two-group kernel takes ~1.97x a 256-sample tile of the one-group kernel (it is 1 - 2 % faster per
+// sample).  The two-group kernel runs when its rounds cost no more: always from 4 rounds on, never when its tiles would leave half
+// the chip idle (65,536 samples: 128 tiles against 256).  DDNERF_BF16_G2_MIN=<samples> replaces the rule by a plain threshold
+// (0: always the two-group kernel, -1: never).
+static bool g2_wanted(long M) {
+    static long forced = -2;
+    static long n_cu = 0;
+    if (forced == -2) {
         const char *e = getenv("DDNERF_BF16_G2_MIN");
-        v = e && *e ? atol(e) : 65536;
+        forced = e && *e ? atol(e) : -3;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    return v;
+    if (forced != -3) return forced >= 0 && M >= forced;
+    const long r2 = ((M + G2_TILE - 1) / G2_TILE + n_cu - 1) / n_cu, r1 = ((M + 255) / 256 + n_cu - 1) / n_cu;
+    return M >= 65536 && 197 * r2 <= 100 * r1;
 }
 DDN_EXPORT size_t ddnerf_mlp_bf16_packed_bytes(int depth_head) { return g2_image_offset(depth_head) + (size_t)G2_IMG_BYTES; }
 DDN_EXPORT int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
@@ -224,8 +235,7 @@ DDN_EXPORT int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *p
 }
 DDN_EXPORT int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream) {
     DDN_REQUIRE(feat && packed && raw, DDNERF_E_ARG);
-    const long lim = g2_min_samples();
-    if (lim >= 0 && M >= lim) return ddnerf_mlp_bf16g2_forward(feat, (const char *)packed + g2_image_offset(depth_head), depth_head, raw, M, stream);
+    if (g2_wanted(M)) return ddnerf_mlp_bf16g2_forward(feat, (const char *)packed + g2_image_offset(depth_head), depth_head, raw, M, stream);
     return ddnerf_mlp_bf16g1_forward(feat, packed, depth_head, raw, M, stream);
 }
 #endif

@@ -88,8 +88,9 @@ int ddnerf_mlp_f32_forward(const float *feat, const float *packed, int depth_hea
  * feat: bf16 [M,128] as written by ddnerf_encode(feat_dtype=1), i.e. in MFMA "k-order": inside every 32
  * columns, position 8g + e (g = 0..3, e = 0..7) holds column 16(e>>2) + 4g + (e&3) -- the order in which two
  * 16x16 accumulator tiles re-enter the next layer's v_mfma_f32_16x16x32_bf16 as its B operand.
- * Two kernels stand behind these three entry points and produce the same bits for the same sample: the forward picks by launch
- * size (M >= 65536, or the value of the environment variable DDNERF_BF16_G2_MIN: the two-group kernel), the weight image holds
+ * Two kernels stand behind these three entry points and produce the same bits for the same sample: the forward picks the one
+ * whose tile rounds cost less at this launch size (the two-group kernel from 65,536 samples on whenever its 512-sample tiles do not
+ * leave CUs idle that 256-sample tiles would use; DDNERF_BF16_G2_MIN=<samples> makes it a plain threshold), the weight image holds
  * both kernels' layouts. */
 size_t ddnerf_mlp_bf16_packed_bytes(int depth_head);
 int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);

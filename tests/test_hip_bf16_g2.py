@@ -68,7 +68,7 @@ def test_entry_point_picks_by_size_and_the_choice_is_invisible(ops, monkeypatch)
     p1 = ops.mlp_bf16g1_pack(flat, False)
     assert packed.numel() > p1.numel() + 1_000_000        # (both images)
     fb = _rows(ops, 100000, 7)
-    big = ops.mlp_bf16_forward(fb, packed, False)                      # >= 65536 samples: the two-group kernel
+    big = ops.mlp_bf16_forward(fb, packed, False)                      # 196 tiles of 512 on 256 CUs: the two-group kernel
     small = torch.cat([ops.mlp_bf16_forward(fb[i:i + 20000].contiguous(), packed, False) for i in range(0, 100000, 20000)])
     ref = ops.mlp_bf16g1_forward(fb, p1, False)
     torch.cuda.synchronize()
