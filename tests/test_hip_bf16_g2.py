@@ -73,3 +73,18 @@ def test_entry_point_picks_by_size_and_the_choice_is_invisible(ops, monkeypatch)
     ref = ops.mlp_bf16g1_forward(fb, p1, False)
     torch.cuda.synchronize()
     assert torch.equal(big, small) and torch.equal(big, ref)
+
+
+def test_many_launches_back_to_back_stay_identical(ops):
+    """A race in the assembly kernel's bookkeeping (a wait one too lax, a barrier too few) would be rare and timing-dependent: 120
+    launches back to back on fresh rows, each compared bit for bit with the one-group kernel (scratch/g2_stress.py runs the same
+    loop for minutes: 35,000 launches without a mismatch on the final build)."""
+    flat = _flat(False, 12, 20.0)
+    p1, p2 = ops.mlp_bf16g1_pack(flat, False), ops.mlp_bf16g2_pack(flat, False)
+    for it in range(40):
+        M = (524288, 262144, 400000 + 977 * it)[it % 3]
+        fb = _rows(ops, M, 1000 + it)
+        a = ops.mlp_bf16g1_forward(fb, p1, False)
+        outs = [ops.mlp_bf16g2_forward(fb, p2, False) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for b in outs), (it, M)
