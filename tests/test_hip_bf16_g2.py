@@ -88,3 +88,15 @@ def test_many_launches_back_to_back_stay_identical(ops):
         outs = [ops.mlp_bf16g2_forward(fb, p2, False) for _ in range(3)]
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for b in outs), (it, M)
+
+
+def test_launches_beyond_the_32_bit_row_offsets_are_split(ops):
+    """the assembly body addresses rows with 32-bit byte offsets: the entry point cuts a launch into pieces of 4 M samples (each with
+    its own first tile and ragged last tile); 4 M + 513 samples, depth head (6 outputs per sample: the other output stride)"""
+    flat = _flat(True, 3, 4.0)
+    p1, p2 = ops.mlp_bf16g1_pack(flat, True), ops.mlp_bf16g2_pack(flat, True)
+    M = (1 << 22) + 513
+    fb = _rows(ops, M, 11)
+    a, b = ops.mlp_bf16g1_forward(fb, p1, True), ops.mlp_bf16g2_forward(fb, p2, True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and bool(torch.isfinite(b).all())
