@@ -76,6 +76,8 @@ def test_operand_ranges_and_counts(gen, body):
             assert m is None or int(m.group(1)) <= 63, t
             m = re.search(r"lgkmcnt\((\d+)\)", t)
             assert m is None or int(m.group(1)) <= 15, t
+    for a, b in zip(lines, lines[1:]):                                       # an SALU write of M0 needs a wait state before the LDS-DMA that uses it
+        assert not (re.match(r"s_\w+ m0,", a) and b.startswith("global_load_lds")), (a, b)
     assert n_mfma == 9640                                                    # 2 groups x 4820: exactly the one-group kernel's per 256 samples
     pro = sum(gen.npw_of(d["chunk"]) for d in gen.real if d["for_next_tile"])
     assert n_dma == 389 + pro                                                # the steady state + the first tile's prologue
