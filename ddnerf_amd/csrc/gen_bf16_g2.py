@@ -38,6 +38,7 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 # bench.py reports).  G2_STAMP_PERIODS=1 in the generator's environment adds a stamp at the end of every period, and per block inside
 # the window STAMP_BLOCKS (scratch/g2_clock.py reads them); each costs a scalar-memory round trip, so they are off by default.
 STAMP_PERIODS = os.environ.get("G2_STAMP_PERIODS", "0") == "1"
+DUMMY_VALU = [int(x) for x in os.environ.get("G2_DUMMY_VALU", "0,0").split(",")]
 STAMP_BLOCKS = (8, 20)
 STAMP_KSTEPS = [tuple(int(v) for v in x.split(":")) for x in os.environ.get("G2_STAMP_KSTEPS", "").split(",") if x]   # (period, block in period): a stamp per k-step
 DMA_SPAN_NUM, DMA_SPAN_DEN = [int(x) for x in os.environ.get("G2_DMA_SPAN", "1/1").split("/")]   # the part of its issue period over which a chunk's LDS-DMA pieces are spread
@@ -532,6 +533,11 @@ class Gen:
                     gaps[(0, 0)].append(("base_h", rowb(K[10]), blk["lds"] // SLOT_BYTES * SLOT_BYTES))
             # re-pack of the previous block: one instruction per gap (gaps 1-3 of the first kmax k-steps)
             ops = self.repack_ops(blocks[i - 1]) if i > 0 else []
+            # (experiment, G2_DUMMY_VALU="v,t": v plain + t transcendental VALU instructions more per block on a register nothing reads --
+            # what an encoder inside this kernel would add to the MFMA gaps)
+            for j in range(DUMMY_VALU[0] + DUMMY_VALU[1]):
+                ops.insert((j * (len(ops) + 1)) // (DUMMY_VALU[0] + DUMMY_VALU[1]) + j if ops else j,
+                           ("v_exp_f32 v%d, v%d" if j < DUMMY_VALU[1] else "v_mul_f32 v%d, 0x3fb8aa3b, v%d") % (V_PF, V_PF))
             slots = [(u, mi) for u in range(kmax) for mi in (1, 2, 3)]
             for t, op in enumerate(ops):
                 gaps[slots[(t * len(slots)) // len(ops)]].append(("op", op))

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:?}; L=scratch/ab/lib
-timeout -k 10 250 python scratch/ab/ab.py bf16 $L/bf16_new.so $L/g2_new.so:bf16g2 "$L/g2_-DG2_STAGGER=2.so:bf16g2" "$L/g2_-DG2_STAGGER=8.so:bf16g2" 2>&1 | grep -v amdgpu.ids
+timeout -k 10 250 python scratch/ab/ab.py bf16 $L/bf16_new.so $L/g2_new.so:bf16g2 $L/g2_dummy_8_2.so:bf16g2 $L/g2_dummy_15_3.so:bf16g2 2>&1 | grep -v amdgpu.ids
