@@ -39,6 +39,9 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 # the window STAMP_BLOCKS (scratch/g2_clock.py reads them); each costs a scalar-memory round trip, so they are off by default.
 STAMP_PERIODS = os.environ.get("G2_STAMP_PERIODS", "0") == "1"
 DUMMY_VALU = [int(x) for x in os.environ.get("G2_DUMMY_VALU", "0,0").split(",")]
+# (experiment, G2_SKIP_FILL=n: every block ends with a branch over n bytes of filler -- n = 0: the branch alone; n = 560: twice the
+# code footprint and twice the 4-KiB boundaries per tile at the same work.  Does code size cost time?  DESIGN.md section 2.1)
+SKIP_FILL = int(os.environ["G2_SKIP_FILL"]) if "G2_SKIP_FILL" in os.environ else None
 STAMP_BLOCKS = (8, 20)
 STAMP_KSTEPS = [tuple(int(v) for v in x.split(":")) for x in os.environ.get("G2_STAMP_KSTEPS", "").split(",") if x]   # (period, block in period): a stamp per k-step
 DMA_SPAN_NUM, DMA_SPAN_DEN = [int(x) for x in os.environ.get("G2_DMA_SPAN", "1/1").split("/")]   # the part of its issue period over which a chunk's LDS-DMA pieces are spread
@@ -587,6 +590,11 @@ class Gen:
                             self.set_bases(*it[1:])
                         elif it[0] == "base_h":
                             self.set_base_h(*it[1:])
+            if SKIP_FILL is not None:
+                self.out.append("\ts_branch .Lskip%%=_%d" % i)
+                if SKIP_FILL:
+                    self.out.append("\t.fill %d, 4, 0xbf800000" % (SKIP_FILL // 4))      # (s_nop 0: never executed)
+                self.out.append(".Lskip%%=_%d:" % i)
             if blk["last"]:
                 serials = [self.last_piece[k] for k in due.get(blk["period"], []) if k in self.last_piece]
                 if serials:
