@@ -48,7 +48,7 @@ CONFIGS = {
     "config_ff_mipnerf.yml": ("llff", "fp32", 4096),
     "config_360_mipnerf.yml": ("real360", "fp32", 8192),
 }
-KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"],
                   "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
 
 
@@ -368,6 +368,8 @@ def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
 
 
 def kernel_source_digest(mlp):
+    """md5 of the kernel's sources; for the generated assembly body of the two-group bf16 kernel: of the generator's OUTPUT (the files
+    the build compiles), so that an experiment switch added to the generator does not disown a profile of the unchanged kernel"""
     h = hashlib.md5()
     for f in KERNEL_SOURCES[mlp]:
         h.update(open(os.path.join(ROOT, "ddnerf_amd", "csrc", f), "rb").read())

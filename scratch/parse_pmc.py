@@ -32,7 +32,7 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
     # factor measured on the same pattern in the same call.
     fetch_true_kb = fk["FETCH_SIZE_raw_KB"] / BF16_FACTOR if mlp == "bf16" else 2 * fk["FETCH_SIZE_raw_KB"]
     traffic = (fetch_true_kb + fk["WRITE_SIZE_KB"]) * 1024
-    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h"], "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"]}[mlp]
+    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"], "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"]}[mlp]
     digest = hashlib.md5()
     for f_ in srcs:
         digest.update(open(os.path.join(R, "ddnerf_amd", "csrc", f_), "rb").read())
