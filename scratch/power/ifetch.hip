@@ -8,6 +8,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// MIX 4: MIX 1 + s_barrier every 128 MFMAs.  MIX 5: MIX 4 + a clock stamp (s_memtime, s_waitcnt, 8-byte global store) every 32 MFMAs.
 // MIX 0: MFMA + 2 VALU.  MIX 1: + one ds_read_b128 per four MFMAs, consumed three reads later behind a counted s_waitcnt (the MLP
 // kernels' A-fragment ring).  MIX 2: + one 16-byte global load per 16 MFMAs from a 1.4 MB buffer (data-side translations and L2 traffic
 // beside the instruction fetch).  MIX 3: both.
@@ -28,14 +29,21 @@ __global__ __launch_bounds__(256, 1) void k(const bf16x8 *__restrict__ src, floa
     for (int it = 0; it < total_mfma / PER; ++it) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            if constexpr ((MIX & 1) != 0) {
+            if constexpr ((MIX & 1) != 0 || MIX >= 4) {
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i & 7]) : "v"(ring[(i >> 2) & 3]), "v"(b));
                 if ((i & 3) == 0) ring[((i >> 2) + 3) & 3] = lds[((i >> 2) & 15) * 64 + lane];
             } else {
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i & 7]) : "v"(a), "v"(b));
             }
             asm volatile("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0" : "+v"(d[i & 7]), "+v"(d[(i + 3) & 7]));
-            if constexpr ((MIX & 2) != 0)
+            if constexpr (MIX >= 4) {
+                if ((i & 127) == 127) __builtin_amdgcn_s_barrier();
+                if (MIX == 5 && (i & 31) == 31) {
+                    const unsigned long long t = __builtin_amdgcn_s_memtime();
+                    if (tid == 0) stamps[1024 + (i >> 5) % 64] = t;
+                }
+            }
+            if constexpr (MIX < 4 && (MIX & 2) != 0)
                 if ((i & 15) == 0) gsum += __builtin_nontemporal_load(gsrc + ((i >> 4) * 2053 % 5000) * 16);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -79,15 +87,13 @@ int main() {
     unsigned long long *stamps;
     hipMalloc(&src, h.size() * 2);
     hipMalloc(&out, (size_t)ncu * 256 * 4);
-    hipMalloc(&stamps, ncu * 8);
+    hipMalloc(&stamps, (ncu + 2048) * 8);
     hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
-    run<24, 0>(src, out, stamps, ncu);
-    run<192, 0>(src, out, stamps, ncu);
     run<24, 1>(src, out, stamps, ncu);
     run<192, 1>(src, out, stamps, ncu);
-    run<24, 2>(src, out, stamps, ncu);
-    run<192, 2>(src, out, stamps, ncu);
-    run<24, 3>(src, out, stamps, ncu);
-    run<192, 3>(src, out, stamps, ncu);
+    run<24, 4>(src, out, stamps, ncu);
+    run<192, 4>(src, out, stamps, ncu);
+    run<24, 5>(src, out, stamps, ncu);
+    run<192, 5>(src, out, stamps, ncu);
     return 0;
 }
