@@ -14,7 +14,7 @@ done
 echo benches done
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_fp32 -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-bf16-tier > $O/p_fp32.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_bf16 -o r -- python3 $R/bench.py --mlp bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-clock > $O/p_bf16.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_bf16 -o r -- python3 $R/bench.py --mlp bf16 --steps 80 --warmup 2 --no-cpu-baseline --no-clock > $O/p_bf16.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_x3 -o r -- python3 $R/bench.py --mlp x3 --steps 10 --warmup 2 --no-cpu-baseline > $O/p_x3.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_train_fp32 -o r -- python3 $R/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $O/p_train_fp32.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_train_x3 -o r -- python3 $R/bench.py --mode train --mlp x3 --steps 5 --warmup 2 --no-cpu-baseline > $O/p_train_x3.log 2>&1
