@@ -42,6 +42,7 @@ DUMMY_VALU = [int(x) for x in os.environ.get("G2_DUMMY_VALU", "0,0").split(",")]
 # (experiment, G2_SKIP_FILL=n: every block ends with a branch over n bytes of filler -- n = 0: the branch alone; n = 560: twice the
 # code footprint and twice the 4-KiB boundaries per tile at the same work.  Does code size cost time?  DESIGN.md section 2.1)
 SKIP_FILL = int(os.environ["G2_SKIP_FILL"]) if "G2_SKIP_FILL" in os.environ else None
+HEAD_PAD = int(os.environ.get("G2_HEAD_PAD", "0"))   # (experiment: the whole body shifted by this many bytes of skipped filler)
 STAMP_BLOCKS = (8, 20)
 STAMP_KSTEPS = [tuple(int(v) for v in x.split(":")) for x in os.environ.get("G2_STAMP_KSTEPS", "").split(",") if x]   # (period, block in period): a stamp per k-step
 DMA_SPAN_NUM, DMA_SPAN_DEN = [int(x) for x in os.environ.get("G2_DMA_SPAN", "1/1").split("/")]   # the part of its issue period over which a chunk's LDS-DMA pieces are spread
@@ -647,6 +648,10 @@ class Gen:
 
     def head(self):
         e = self.e
+        if HEAD_PAD:
+            self.out.append("\ts_branch .Lpad%=")
+            self.out.append("\t.fill %d, 4, 0xbf800000" % (HEAD_PAD // 4))
+            self.out.append(".Lpad%=:")
         e("s_lshl_b32 s%d, %%5, 10" % S_SWAVE)
         e("s_lshl_b32 s%d, %%6, 17" % S_TB)           # tile * 512 rows * 256 bytes
         e("s_lshl_b32 s%d, %%5, 15" % S_T0)           # wave * 128 rows
