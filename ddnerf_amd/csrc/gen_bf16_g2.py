@@ -42,6 +42,7 @@ DUMMY_VALU = [int(x) for x in os.environ.get("G2_DUMMY_VALU", "0,0").split(",")]
 # (experiment, G2_SKIP_FILL=n: every block ends with a branch over n bytes of filler -- n = 0: the branch alone; n = 560: twice the
 # code footprint and twice the 4-KiB boundaries per tile at the same work.  Does code size cost time?  DESIGN.md section 2.1)
 SKIP_FILL = int(os.environ["G2_SKIP_FILL"]) if "G2_SKIP_FILL" in os.environ else None
+SKIP_EVERY = int(os.environ.get("G2_SKIP_EVERY", "1"))   # (... only behind every n-th block)
 HEAD_PAD = int(os.environ.get("G2_HEAD_PAD", "0"))   # (experiment: the whole body shifted by this many bytes of skipped filler)
 STAMP_BLOCKS = (8, 20)
 STAMP_KSTEPS = [tuple(int(v) for v in x.split(":")) for x in os.environ.get("G2_STAMP_KSTEPS", "").split(",") if x]   # (period, block in period): a stamp per k-step
@@ -591,7 +592,7 @@ class Gen:
                             self.set_bases(*it[1:])
                         elif it[0] == "base_h":
                             self.set_base_h(*it[1:])
-            if SKIP_FILL is not None:
+            if SKIP_FILL is not None and i % SKIP_EVERY == SKIP_EVERY - 1:
                 self.out.append("\ts_branch .Lskip%%=_%d" % i)
                 if SKIP_FILL:
                     self.out.append("\t.fill %d, 4, 0xbf800000" % (SKIP_FILL // 4))      # (s_nop 0: never executed)
