@@ -35,18 +35,63 @@ SLOT_BYTES = 36 * 1024
 NSLOT = 4
 DEPTH = 4        # A fragments are read this many k-steps ahead
 # Diagnostic (-DBF16_STAMP) builds: the C++ shell stamps the tile loop of every workgroup (in-kernel clock, cycles per tile: what
-# bench.py reports).  G2_STAMP_PERIODS=1 in the generator's environment adds a stamp at the end of every period, and per block inside
-# the window STAMP_BLOCKS (scratch/g2_clock.py reads them); each costs a scalar-memory round trip, so they are off by default.
-STAMP_PERIODS = os.environ.get("G2_STAMP_PERIODS", "0") == "1"
-DUMMY_VALU = [int(x) for x in os.environ.get("G2_DUMMY_VALU", "0,0").split(",")]
-# (experiment, G2_SKIP_FILL=n: every block ends with a branch over n bytes of filler -- n = 0: the branch alone; n = 560: twice the
-# code footprint and twice the 4-KiB boundaries per tile at the same work.  Does code size cost time?  DESIGN.md section 2.1)
-SKIP_FILL = int(os.environ["G2_SKIP_FILL"]) if "G2_SKIP_FILL" in os.environ else None
-SKIP_EVERY = int(os.environ.get("G2_SKIP_EVERY", "1"))   # (... only behind every n-th block)
-HEAD_PAD = int(os.environ.get("G2_HEAD_PAD", "0"))   # (experiment: the whole body shifted by this many bytes of skipped filler)
+# bench.py reports).
+#
+# EXPERIMENT SWITCHES.  They come from `--experiment key=value` on the generator's command line and from nowhere else (never the
+# environment: a variable left over in a shell must not change the product kernel); `python gen_bf16_g2.py outdir` with no switch is
+# the product body.  The switches in force are recorded in the generated tables (G2_GENERATOR_OPTIONS -> ddnerf_build_info()).
+#   stamp_periods=1   (stamp builds) a stamp at the end of every period and per block inside the window STAMP_BLOCKS (tools/g2_clock.py
+#                     reads them); each costs a scalar-memory round trip and an LDS drain
+#   stamp_ksteps=p:b,...  (with stamp_periods) a stamp per k-step of block b of period p
+#   sgpr_stamps=b0:b1 (stamp builds) ONE s_memtime per block boundary of blocks b0..b1 (at most 20 values) into SGPRs of their own,
+#                     written out at the end of the tile: no wait, no store inside the window (8 bytes of code per stamp)
+#   dummy_valu=v,t    v plain + t transcendental VALU instructions more per block on a register nothing reads
+#   skip_fill=n / skip_every=m   every m-th block ends with a branch over n bytes of filler
+#   head_pad=n        the whole body shifted by n bytes of skipped filler
+#   align=n           the body's first instruction aligned to 2^n bytes (.p2align)
+#   dma_span=a/b      the part of its issue period over which a chunk's LDS-DMA pieces are spread
+#   touch=<file>      code-page touch: every block starts with an s_load_dword from the code address listed for it in <file> (one signed
+#                     byte offset from the s_getpc at the body's top per block; `nop` = a filler of the same size) -- see tools/g2_touch.py
+#   nodma=1 / nox=1   TIMING ONLY, results wrong: no LDS-DMA pieces / no feature fetches are issued
+EXP_DEFAULT = dict(stamp_periods="0", stamp_ksteps="", sgpr_stamps="", dummy_valu="0,0", skip_fill="", skip_every="1", head_pad="0", align="0",
+                   dma_span="1/1", touch="", nodma="0", nox="0")
+EXP = dict(EXP_DEFAULT)
+
+
+def set_experiment(opts):
+    """install experiment switches (dict key -> string); unknown keys are an error"""
+    global STAMP_PERIODS, DUMMY_VALU, SKIP_FILL, SKIP_EVERY, HEAD_PAD, ALIGN, STAMP_KSTEPS, DMA_SPAN_NUM, DMA_SPAN_DEN, SGPR_STAMPS, TOUCH, NODMA, NOX
+    for k in opts:
+        if k not in EXP_DEFAULT:
+            raise SystemExit("gen_bf16_g2: unknown experiment switch %r (known: %s)" % (k, ", ".join(sorted(EXP_DEFAULT))))
+    EXP.clear()
+    EXP.update(EXP_DEFAULT)
+    EXP.update(opts)
+    STAMP_PERIODS = EXP["stamp_periods"] == "1"
+    DUMMY_VALU = [int(x) for x in EXP["dummy_valu"].split(",")]
+    SKIP_FILL = int(EXP["skip_fill"]) if EXP["skip_fill"] != "" else None
+    SKIP_EVERY = int(EXP["skip_every"])
+    HEAD_PAD = int(EXP["head_pad"])
+    ALIGN = int(EXP["align"])
+    STAMP_KSTEPS = [tuple(int(v) for v in x.split(":")) for x in EXP["stamp_ksteps"].split(",") if x]   # (period, block in period)
+    DMA_SPAN_NUM, DMA_SPAN_DEN = [int(x) for x in EXP["dma_span"].split("/")]
+    SGPR_STAMPS = tuple(int(v) for v in EXP["sgpr_stamps"].split(":")) if EXP["sgpr_stamps"] else None
+    if SGPR_STAMPS:
+        assert 0 <= SGPR_STAMPS[0] < SGPR_STAMPS[1] and SGPR_STAMPS[1] - SGPR_STAMPS[0] <= NSTAMP_SGPR - 1, "sgpr_stamps: at most %d blocks" % (NSTAMP_SGPR - 1)
+    TOUCH = [x for x in open(EXP["touch"]).read().split()] if EXP["touch"] else None
+    NODMA, NOX = EXP["nodma"] == "1", EXP["nox"] == "1"
+
+
+def options_string():
+    """the switches that differ from the product's, "key=value ..." ("" = product body)"""
+    return " ".join("%s=%s" % (k, EXP[k]) for k in sorted(EXP) if EXP[k] != EXP_DEFAULT[k])
+
+
+NSTAMP_SGPR = 20     # s[44:83]: 20 s_memtime values of the sgpr_stamps experiment
+S_STAMP0 = 44
+S_PC, S_JUNK = 98, 92    # touch experiment: s[98:99] = the address behind the body's s_getpc, s92 = where the touched word goes
 STAMP_BLOCKS = (8, 20)
-STAMP_KSTEPS = [tuple(int(v) for v in x.split(":")) for x in os.environ.get("G2_STAMP_KSTEPS", "").split(",") if x]   # (period, block in period): a stamp per k-step
-DMA_SPAN_NUM, DMA_SPAN_DEN = [int(x) for x in os.environ.get("G2_DMA_SPAN", "1/1").split("/")]   # the part of its issue period over which a chunk's LDS-DMA pieces are spread
+set_experiment({})
 FEAT_ROW = 256   # bytes of one encoded sample (DDNERF_FEAT_LD bf16)
 TILE = 512
 
@@ -266,7 +311,8 @@ class Gen:
         kind, r = dst
         self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, (g * 64 + c * 16) * FEAT_ROW))
         self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
-        self.e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d nt" % (reg(kind, r, 4), V_TMP1, 64 * q))
+        if not NOX:
+            self.e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d nt" % (reg(kind, r, 4), V_TMP1, 64 * q))
         self.vm_issue("x", key)
 
     def prefetch(self, nxt, g, line):
@@ -275,7 +321,8 @@ class Gen:
         self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, g * 64 * FEAT_ROW))
         self.e("v_lshlrev_b32 v%d, 4, v%d" % (V_TMP1, V_LANE16))
         self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_TMP1))
-        self.e("buffer_load_dword v%d, v%d, %%0, 0 offen offset:%d" % (V_PF, V_TMP1, 128 * line))
+        if not NOX:
+            self.e("buffer_load_dword v%d, v%d, %%0, 0 offen offset:%d" % (V_PF, V_TMP1, 128 * line))
         self.vm_issue("x")
 
     def dma_setup(self, img, lds, npw):
@@ -287,7 +334,8 @@ class Gen:
         self.e("s_add_u32 m0, s%d, %%4" % S_T1)
 
     def dma_piece(self, imm, key=None, last=False):
-        self.e("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d" % (V_LANE16, S_CUR, S_CUR + 1, imm))
+        if not NODMA:
+            self.e("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d" % (V_LANE16, S_CUR, S_CUR + 1, imm))
         serial = self.vm_issue("dma")
         if last:
             self.last_piece[key] = serial
@@ -526,6 +574,15 @@ class Gen:
             nks = len(order)
             kmax = nks if nks <= 4 else min(nks - 1, 7)
             self.comment("---- block %d: layer %d block %d group %d (period %d)" % (i, l, b, g, blk["period"]))
+            if TOUCH is not None:       # (experiment: 8 bytes per block either way, so that a second pass over the addresses changes no address)
+                if TOUCH[i] == "nop":
+                    self.e("s_nop 0")
+                    self.e("s_nop 0")
+                else:
+                    self.e("s_load_dword s%d, s[%d:%d], 0x%x" % (S_JUNK, S_PC, S_PC + 1, int(TOUCH[i])))
+            if self.stamp and SGPR_STAMPS and SGPR_STAMPS[0] <= i <= SGPR_STAMPS[1]:
+                j = i - SGPR_STAMPS[0]
+                self.e("s_memtime s[%d:%d]" % (S_STAMP0 + 2 * j, S_STAMP0 + 2 * j + 1))
             gaps = defaultdict(list)
             if blk["first"]:
                 period_mark = self.vm_serial
@@ -613,6 +670,15 @@ class Gen:
             if blk["last"]:
                 self.stamp_pass(blk["period"] + 1)          # (diagnostic builds: the clock at the end of every period; slot 0: tile begin)
         self.lg_flush()
+        if self.stamp and SGPR_STAMPS:      # (the window's block-boundary clocks leave the SGPRs here, behind the tile's last wait)
+            self.e("s_mov_b64 exec, s[%d:%d]" % (S_SEXEC, S_SEXEC + 1))
+            for j in range(SGPR_STAMPS[1] - SGPR_STAMPS[0] + 1):
+                self.e("v_mov_b32 v%d, s%d" % (V_STAMP, S_STAMP0 + 2 * j))
+                self.e("v_mov_b32 v%d, s%d" % (V_STAMP + 1, S_STAMP0 + 2 * j + 1))
+                self.e("s_nop 0")
+                self.e("global_store_dwordx2 v%d, v[%d:%d], %%9 offset:%d" % (V_ZERO, V_STAMP, V_STAMP + 1, 8 * (150 + j)))
+                self.vm_issue("store")
+            self.e("s_mov_b64 exec, -1")
         return blocks, NK
 
     def prologue(self):
@@ -649,6 +715,12 @@ class Gen:
 
     def head(self):
         e = self.e
+        if TOUCH is not None:
+            e("s_getpc_b64 s[%d:%d]" % (S_PC, S_PC + 1))
+        if ALIGN:
+            self.out.append("\ts_branch .Lal%=")
+            self.out.append("\t.p2align %d" % ALIGN)
+            self.out.append(".Lal%=:")
         if HEAD_PAD:
             self.out.append("\ts_branch .Lpad%=")
             self.out.append("\t.fill %d, 4, 0xbf800000" % (HEAD_PAD // 4))
@@ -663,7 +735,7 @@ class Gen:
         e("s_lshl_b32 s%d, %%5, 7" % S_T0)
         e("s_add_u32 s%d, s%d, s%d" % (S_RB, S_RB, S_T0))
         e("s_mul_i32 s%d, s%d, %d" % (S_RB, S_RB, self.rs))
-        if self.stamp and STAMP_PERIODS:
+        if self.stamp and (STAMP_PERIODS or SGPR_STAMPS):
             e("s_cmp_eq_u32 %5, 0")
             e("s_cselect_b64 s[%d:%d], 1, 0" % (S_SEXEC, S_SEXEC + 1))
         e("s_cmp_lg_u32 %6, %8")
@@ -697,13 +769,21 @@ def tables(blocks):
     t.append("#define G2_IMG_BYTES %d" % IMG_BYTES)
     t.append("#define G2_NSLICE %d" % len(slices))
     t.append("static constexpr int kG2Slice[G2_NSLICE][3] = {%s};" % ", ".join("{%d, %d, %d}" % s for s in slices))
-    regs = ['"v%d"' % i for i in range(256)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in S_CLOBBER]
+    sregs = list(S_CLOBBER) + (list(range(S_STAMP0, S_STAMP0 + 2 * NSTAMP_SGPR)) if SGPR_STAMPS else []) + ([S_PC, S_PC + 1] if TOUCH is not None else [])
+    t.append("#define G2_GENERATOR_OPTIONS \"%s\"" % options_string())
+    regs = ['"v%d"' % i for i in range(256)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in sregs]
     t.append("#define G2_CLOBBERS %s, \"vcc\", \"scc\", \"memory\"" % ", ".join(regs))
     return t
 
 
 if __name__ == "__main__":
-    outdir = sys.argv[1]
+    import argparse
+    ap = argparse.ArgumentParser(description="generate the tile bodies of mlp_bf16_g2.hip")
+    ap.add_argument("outdir")
+    ap.add_argument("--experiment", action="append", default=[], metavar="key=value", help="experiment switch (see the header); none = the product body")
+    args = ap.parse_args()
+    set_experiment(dict(x.split("=", 1) for x in args.experiment))
+    outdir = args.outdir
     nlines = 0
     for depth_head in (0, 1):
         for stamp in (0, 1):
