@@ -70,13 +70,25 @@ def parse(argv=None):
     p.add_argument("--ramp", type=int, default=None, help="untimed steps BEFORE the W warm-up steps: the power-limited bf16 / x3 kernels need "
                    "about 30 steps of sustained load before the chip's clock settles (3 warm-up steps: fine MLP 0.422 ms, 30 or more: 0.404); "
                    "default 40 for the bf16 / x3 render pass, 0 otherwise")
+    p.add_argument("--single-rank-rccl", action="store_true", help="run the N > 1 code path (RCCL process group, barrier fences, MAX all-reduce of the "
+                   "time, the train leg with its gradient all-reduce) on a ONE-rank group: how a one-GPU box executes those lines (tests/test_bench_contract.py)")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend of the N > 1 path; gloo only for rehearsals")
+    p.add_argument("--share-gpu", action="store_true", help="rehearsal on a box with fewer GPUs than ranks: rank r uses GPU r %% (GPUs present); needs --backend gloo "
+                   "(RCCL refuses two ranks on one device)")
+    p.add_argument("--image", default=None, metavar="HxW", help="also render one full validation image of this size through run_iter (all its ray chunks) and "
+                   "report seconds per image beside the per-chunk figure (eval_nerf.py's product-level timing)")
     p.add_argument("--no-clock", action="store_true", help="skip the bf16 line's in-kernel clock measurement (thousands of launches of the "
                    "diagnostic build: they would drown the product kernel in a profiler's per-kernel statistics)")
     args = p.parse_args(argv)
     kind, mlp, rays = CONFIGS[args.config]
     args.ray_kind = kind
     args.mlp = args.mlp or mlp
-    args.mode = args.mode or ("render" if args.gpus == 1 else "both")
+    args.mode = args.mode or ("render" if (args.gpus == 1 and not args.single_rank_rccl) else "both")
+    if args.share_gpu and args.backend != "gloo":
+        p.error("--share-gpu needs --backend gloo")
+    if args.image:
+        h, w = args.image.lower().split("x")
+        args.image = (int(h), int(w))
     if args.ramp is None:
         args.ramp = TIER_RAMP if (args.mlp in ("bf16", "x3") and args.mode == "render") else 0
     args.scaling = "strong" if args.global_rays else "weak"
@@ -155,7 +167,7 @@ def launch_ranks(args, argv):
     import torch
 
     have = torch.cuda.device_count()  # (does not initialise the GPU)
-    if have < args.gpus:
+    if have < (1 if args.share_gpu else args.gpus):
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
     port = free_port()
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
@@ -401,12 +413,12 @@ def main(argv=None):
                          "with --nproc-per-node N)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    dist = world > 1 or args.single_rank_rccl   # (--single-rank-rccl: the N > 1 code path on a one-rank group, for one-GPU boxes)
 
     # The other tiers are measured by child runs BEFORE this process touches the GPU: a child that shares the card with an idle
     # parent context measures the launch-heavy bf16 step up to 1.6x slower than a run of its own (0.89 -> 1.39 ms).
     tiers = {}
-    if world == 1 and args.mode == "render" and args.mlp == "fp32" and args.config == "config_blender.yml" and not args.no_bf16_tier:
+    if world == 1 and not dist and args.mode == "render" and args.mlp == "fp32" and args.config == "config_blender.yml" and not args.no_bf16_tier:
         tiers["x3_tier"] = extra_tier(args, "x3")
         tiers["bf16_tier"] = extra_tier(args, "bf16")
         tiers["train_tier"] = {"fp32": train_tier(args, "fp32"), "x3": train_tier(args, "x3")}
@@ -415,6 +427,8 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    if args.share_gpu:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     backend = None
@@ -423,9 +437,13 @@ def main(argv=None):
 
         import datetime
 
+        if env_world is None:   # --single-rank-rccl without a launcher: a rendezvous of one
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         # "nccl" IS RCCL on ROCm; a bounded collective timeout: a rank whose peer died fails instead of waiting 10 minutes
-        td.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=int(os.environ.get("DDNERF_PG_TIMEOUT_S", "300"))))
-        backend = "%s (RCCL)" % td.get_backend()
+        kw = {"device_id": device} if args.backend == "nccl" else {}
+        td.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("DDNERF_PG_TIMEOUT_S", "300"))), **kw)
+        backend = "%s (RCCL)" % td.get_backend() if args.backend == "nccl" else "%s (rehearsal: not the measured configuration)" % td.get_backend()
     from ddnerf_amd import ops, synthetic
 
     model, cfg, sd_c, sd_f = build_model(args, device)
@@ -469,13 +487,18 @@ def main(argv=None):
                 return model.run_iter(ro, rd, rad, mode="validation", rgb_target=tgt)
 
         res["render"] = (timed(render_step), timer.mean_ms(M_fine))
-    if args.mode in ("train", "both"):
-        if args.mlp == "bf16":
+    train_skipped = None
+    if args.mode in ("train", "both") and args.mlp == "bf16":
+        # there is no bf16 training tier (the reference trains in fp32; ddnerf_amd/functions.py raises)
+        if args.mode == "train":
             raise SystemExit("bench.py: training runs on the fp32 / x3 MLP kernels (--mlp fp32|x3)")
+        train_skipped = "no training leg: --mlp bf16 is an inference-only kernel (training runs on --mlp fp32 | x3)"
+    elif args.mode in ("train", "both"):
         from ddnerf_amd import train_step
 
-        stepper = train_step.TrainStepper(model, cfg, dist=dist)
+        stepper = train_step.TrainStepper(model, cfg, dist=dist, single_rank_collectives=args.single_rank_rccl)
         res["train"] = (timed(lambda: stepper.step(ro, rd, rad, tgt)), timer.mean_ms(M_fine))
+    image = image_pass(args, model, device, fence) if (args.image and "render" in res) else None
 
     if rank == 0:
         head = "render" if "render" in res else "train"
@@ -488,13 +511,14 @@ def main(argv=None):
             ach = M_fine * FLOP_FINE / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "mlp_%s_fwd_kernel<fine> (%d samples/launch)" % (args.mlp, M_fine),
                     "achieved": round(ach, 2), "peak": PEAK[args.mlp], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK[args.mlp], 4), "traffic": traffic, "traffic_source": src,
+                    "frac": round(ach / PEAK[args.mlp], 4), "traffic": traffic, "traffic_source": src, "traffic_measured_in_run": False,
                     "launch_ms": round(ms, 4), "launches_timed": launches}
             if args.mlp == "x3":
                 roof["issued_tflops"] = round(3 * ach, 2)
                 roof["frac_issued"] = round(3 * ach / PEAK["x3"], 4)
             if args.mlp == "bf16" and (args.rays, args.fine) == (4096, 128) and not args.no_clock:
                 roof["clock"] = bf16_in_kernel_clock(model.fine.flat_params().detach(), device)
+                roof["ceiling_same_box"] = bf16_same_box_ceiling(device, roof["frac"])
         elif head == "train":
             roof = train_roofline(args, cfg, dt / args.steps)
         net = "DDNerfModel" if cfg.nerf.type == "DDNerfModel" else "GeneralMipNerfModel (one shared MLP)"
@@ -513,6 +537,10 @@ def main(argv=None):
         if dist:
             line["rccl_ranks"] = td.get_world_size()
             line["backend"] = backend
+        if train_skipped:
+            line["train"] = {"skipped": train_skipped}
+        if image:
+            line["image"] = image
         if head == "render" and "train" in res:
             tdt = res["train"][0]
             line["train"] = {"value": round(world * args.rays * args.steps / tdt, 1), "unit": "rays/s",
@@ -525,6 +553,90 @@ def main(argv=None):
         print(json.dumps(line), flush=True)
     if dist:
         td.destroy_process_group()
+
+
+def image_pass(args, model, device, fence):
+    """One full validation image through run_iter, all its ray chunks (eval_nerf.py:103-111 times exactly this call): the product-level
+    figure beside the per-chunk one.  Rays of the image are resident in HBM; 2 untimed images, then 3 timed ones."""
+    import torch
+
+    from ddnerf_amd import synthetic
+
+    h, w = args.image
+    ro, rd, rad, _ = (torch.from_numpy(x).to(device) for x in synthetic.make_rays(args.ray_kind, h * w, 7))
+    ro, rd, rad = ro.view(h, w, 3), rd.view(h, w, 3), rad.view(h, w, 1)
+
+    def one():
+        with torch.no_grad():
+            return model.run_iter(ro, rd, rad, mode="validation")
+
+    for _ in range(2):
+        one()
+    fence()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        out = one()
+    fence()
+    dt = (time.perf_counter() - t0) / n
+    chunk = int(getattr(model.cfg.nerf.validation, "chunksize", 0) or 0)
+    return {"size": "%dx%d" % (h, w), "rays": h * w, "s_per_image": round(dt, 5), "rays_per_s": round(h * w / dt, 1),
+            "chunks": -(-h * w // chunk) if chunk else None, "chunk_rays": chunk or None, "images_timed": n,
+            "rgb_shape": list(out[len(out) - 1]["rgb"].shape)}
+
+
+def bf16_same_box_ceiling(device, kernel_frac, seconds=0.45):
+    """What bare bf16 MFMA loops sustain on THIS device, right behind the timed region (the chip is power-limited on them and devices
+    differ by several per cent): the diagnostic library's ddnerf_debug_mfma_ceiling (csrc/mfma_ceiling.hip) -- 16x16x32 MFMAs at the
+    MLP kernels' per-wave tile with operands in registers, with the A fragments from LDS at the kernels' ratio, and with the kernels'
+    weight staging (LDS-DMA at their rate, a barrier per period) on top -- each for `seconds` of back-to-back launches on uniform(-1, 1)
+    bf16 operands; fractions of the nominal 2.5 PFLOP/s."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from ddnerf_amd import build as hip_build
+
+    if not os.path.exists(hip_build.DIAG_SO):
+        return None
+    L = C.CDLL(hip_build.DIAG_SO)
+    if not hasattr(L, "ddnerf_debug_mfma_ceiling"):
+        return None
+    V = C.c_void_p
+    L.ddnerf_debug_mfma_ceiling_src_bytes.restype = C.c_size_t
+    nb = L.ddnerf_debug_mfma_ceiling_src_bytes()
+    f = L.ddnerf_debug_mfma_ceiling
+    f.argtypes = [C.c_int, V, V, C.c_int, V, V]
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    src = (torch.rand(nb // 2, device=device) * 2 - 1).to(torch.bfloat16).contiguous()
+    out = torch.empty(n_cu * 256, device=device)
+    stamps = torch.zeros(n_cu * 2, dtype=torch.int64, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    iters = 20000                                   # x 96 MFMAs x 16 cycles = 30.7 M cycles ~ 15 ms per launch
+    flop = n_cu * 4 * iters * 96 * (16 * 16 * 32 * 2)
+    res = {}
+    for mode, name in ((0, "registers"), (1, "lds_fed"), (2, "lds_fed_staged")):
+        t0 = time.time()
+        while time.time() - t0 < seconds:
+            for _ in range(4):
+                if f(mode, src.data_ptr(), out.data_ptr(), iters, stamps.data_ptr(), st):
+                    return None
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            f(mode, src.data_ptr(), out.data_ptr(), iters, stamps.data_ptr(), st)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 4
+        s = stamps.cpu().numpy().reshape(n_cu, 2).astype(np.float64)
+        res[name] = {"frac": round(flop / (ms * 1e-3) / 1e12 / PEAK["bf16"], 4), "in_kernel_clock_mhz": round(float(np.median(s[:, 0] / s[:, 1] * 100.0))),
+                     "mfma_busy": round(iters * 96 * 16 / float(np.median(s[:, 0])), 4)}
+    res["kernel_frac_over_staged_ceiling"] = round(kernel_frac / res["lds_fed_staged"]["frac"], 4)
+    res["how"] = ("bare v_mfma_f32_16x16x32_bf16 loops (csrc/mfma_ceiling.hip, diagnostic library), one wave per SIMD on every CU, uniform(-1, 1) bf16 "
+                  "operands, %.2f s of back-to-back launches each, on this device right after the timed region; fractions of 2500 TFLOP/s" % seconds)
+    return res
 
 
 def train_roofline(args, cfg, step_s):

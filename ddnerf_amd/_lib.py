@@ -13,6 +13,7 @@ c_fp = C.c_void_p
 _SIGS = {
     "ddnerf_abi_version": (C.c_int, []),
     "ddnerf_error_string": (C.c_char_p, [C.c_int]),
+    "ddnerf_build_info": (C.c_char_p, []),
     "ddnerf_pack_rays": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, C.c_int, c_fp]),
     "ddnerf_sample_first_cycle": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
     "ddnerf_encode": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp]),

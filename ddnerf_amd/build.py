@@ -87,11 +87,11 @@ DIAG_SO = os.path.join(CSRC, "libddnerf_diag.so")
 
 def build_diag(force: bool = False, verbose: bool = False) -> str:
     deps = [os.path.join(CSRC, f) for f in ("mlp_bf16.hip", "mlp_bf16_g2.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h", "common.h",
-                                            "api.hip")] + [__file__]
+                                            "api.hip", "mfma_ceiling.hip")] + [__file__]
     if force or _stale(DIAG_SO, deps):
         generate(force, verbose)
         cmd = [HIPCC] + COMMON + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_STAMP", "-DBF16_DISPATCH", "-shared", os.path.join(CSRC, "mlp_bf16.hip"),
-                                  os.path.join(CSRC, "mlp_bf16_g2.hip"), os.path.join(CSRC, "api.hip"), "-o", DIAG_SO]
+                                  os.path.join(CSRC, "mlp_bf16_g2.hip"), os.path.join(CSRC, "api.hip"), os.path.join(CSRC, "mfma_ceiling.hip"), "-o", DIAG_SO]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -108,7 +108,9 @@ G2_TABLES = os.path.join(CSRC, "mlp_bf16_g2_tables.gen.inc")   # (written last b
 def generate(force: bool = False, verbose: bool = False) -> None:
     """generated sources: the tile body of mlp_bf16_g2.hip"""
     gen = os.path.join(CSRC, "gen_bf16_g2.py")
-    if force or _stale(G2_TABLES, [gen]):
+    # the product body is generated with NO experiment switch (they exist only as --experiment arguments of the generator, which this
+    # build never passes); tables that record switches -- someone generated an experiment body into csrc/ -- are regenerated
+    if force or _stale(G2_TABLES, [gen]) or '#define G2_GENERATOR_OPTIONS ""' not in open(G2_TABLES).read():
         out = subprocess.check_output([sys.executable, gen, CSRC], text=True)
         if verbose:
             print(out.strip(), flush=True)

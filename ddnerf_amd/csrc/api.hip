@@ -1,7 +1,27 @@
 // ABI version and error strings of libddnerf_hip.so.
 #include "common.h"
+#include <cstdio>
 
 DDN_EXPORT int ddnerf_abi_version(void) { return 1; }
+
+// (mlp_bf16_g2.hip: the experiment switches its generated tile body was produced with; "" = the product body)
+extern "C" const char *ddnerf_bf16g2_generator_options(void);
+
+DDN_EXPORT const char *ddnerf_build_info(void) {
+    static const struct Info {
+        char text[512];
+        Info() {
+#ifdef BF16_STAMP
+            const char *kind = "diagnostic build (clock stamps in the bf16 kernels)";
+#else
+            const char *kind = "product build";
+#endif
+            snprintf(text, sizeof(text), "libddnerf_hip abi 1, gfx950, %s; bf16 two-group body generator options: \"%s\"", kind,
+                     ddnerf_bf16g2_generator_options());
+        }
+    } info;
+    return info.text;
+}
 
 DDN_EXPORT const char *ddnerf_error_string(int code) {
     switch (code) {

@@ -17,6 +17,22 @@ static inline int ddn_launch_status() {
         if (!(cond)) return (code); \
     } while (0)
 
+// CU count of the CURRENT device (a process may drive parts with different counts): looked up per device id, safe to call from
+// several host threads at once (an entry is only ever written with its one value; the attribute query is cheap, unlike
+// hipGetDeviceProperties).  Never 0: the persistent kernels' launchers divide by it.
+static inline int ddn_cu_count() {
+    static int table[64];   // (zero-initialised; int loads / stores of one aligned word)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    const bool tabled = dev >= 0 && dev < 64;
+    int n = tabled ? __atomic_load_n(&table[dev], __ATOMIC_RELAXED) : 0;
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        if (tabled) __atomic_store_n(&table[dev], n, __ATOMIC_RELAXED);
+    }
+    return n;
+}
+
 static inline bool ddn_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // ---- fp32 special functions, written with the reference's operation order -------------------------------

@@ -9,6 +9,8 @@
 
 #include "mlp_bf16_g2_tables.gen.inc"
 
+extern "C" __attribute__((visibility("default"))) const char *ddnerf_bf16g2_generator_options(void) { return G2_GENERATOR_OPTIONS; }
+
 #define G2_SLOT_BYTES (36 * 1024)
 #define G2_LDS_BYTES (4 * G2_SLOT_BYTES)
 #define G2_TILE 512
@@ -123,7 +125,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2_fwd_kernel(const char *__re
     const unsigned plo = (unsigned)(size_t)packed, phi = (unsigned)((size_t)packed >> 32);
     const unsigned grid = gridDim.x, tile0 = blockIdx.x;
 #ifdef BF16_STAMP
-    unsigned long long *const wg_stamps = g_bf16g2_stamps ? g_bf16g2_stamps + 6 * 256 + 192 * blockIdx.x : nullptr;
+    // (layout of the stamp buffer: six values per workgroup for the whole grid, then 192 values per workgroup: sized by the GRID, so a
+    // part with another CU count neither overruns the buffer nor overlaps the two areas)
+    unsigned long long *const wg_stamps = g_bf16g2_stamps ? g_bf16g2_stamps + 6 * gridDim.x + 192 * blockIdx.x : nullptr;
     const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned done = 0;
@@ -179,13 +183,7 @@ DDN_EXPORT int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, i
     DDN_REQUIRE(feat && packed && raw, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16), DDNERF_E_ALIGN);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DDNERF_E_ARG;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = ddn_cu_count();
     for (long m0 = 0; m0 < M; m0 += G2_MAX_LAUNCH) {
         const long m = M - m0 < G2_MAX_LAUNCH ? M - m0 : G2_MAX_LAUNCH;
         const long ntiles = (m + G2_TILE - 1) / G2_TILE;
@@ -213,16 +211,13 @@ static size_t g2_image_offset(int depth_head) { return (ddnerf_mlp_bf16g1_packed
 // the chip idle (65,536 samples: 128 tiles against 256).  DDNERF_BF16_G2_MIN=<samples> replaces the rule by a plain threshold
 // (0: always the two-group kernel, -1: never).
 static bool g2_wanted(long M) {
-    static long forced = -2;
-    static long n_cu = 0;
-    if (forced == -2) {
+    // (a function-local static with an initialiser: initialised exactly once, thread-safe; -3 = no override)
+    static const long forced = [] {
         const char *e = getenv("DDNERF_BF16_G2_MIN");
-        forced = e && *e ? atol(e) : -3;
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+        return e && *e ? atol(e) : -3L;
+    }();
     if (forced != -3) return forced >= 0 && M >= forced;
+    const long n_cu = ddn_cu_count();
     const long r2 = ((M + G2_TILE - 1) / G2_TILE + n_cu - 1) / n_cu, r1 = ((M + 255) / 256 + n_cu - 1) / n_cu;
     return M >= 65536 && 197 * r2 <= 100 * r1;
 }

@@ -115,14 +115,24 @@ class GeneralMipNerfModel(torch.nn.Module):
             rgb_targets = get_minibatches(rgb_target.reshape(-1, 3), chunksize=getattr(self.cfg.nerf, mode).chunksize)
         else:
             rgb_targets = [None for _ in batches]
-        pred = [self.predict(b, mode, depth_analysis_validation, t) for b, t in zip(batches, rgb_targets)]
+        # Several chunks (a validation image is 40 of them): every chunk is ENQUEUED before the host waits for anything -- the one
+        # data-dependent shape per chunk (the DD records' length) is collected after the loop, not inside it, so the GPU never
+        # drains between chunks -- and every output key is concatenated ONCE over all chunks (the reference's pairwise torch.cat in
+        # a loop, :53-61, copies the growing prefix again for every chunk; the result is the same tensor).
+        self._deferred_records = [] if len(batches) > 1 else None
+        try:
+            pred = [self.predict(b, mode, depth_analysis_validation, t) for b, t in zip(batches, rgb_targets)]
+            for finish in (self._deferred_records or []):
+                finish()
+        finally:
+            self._deferred_records = None
         output = pred[0]
-        for i in range(1, len(pred)):
+        if len(pred) > 1:
             for j in range(len(output)):
-                for key in pred[i][j].keys():
-                    v = pred[i][j][key]
-                    if (v is not None) and (v is not False):
-                        output[j][key] = torch.cat((output[j][key], v), dim=0)
+                for key in list(output[j].keys()):
+                    vs = [p[j][key] for p in pred[1:] if key in p[j] and (p[j][key] is not None) and (p[j][key] is not False)]
+                    if vs:
+                        output[j][key] = torch.cat([output[j][key]] + vs, dim=0)
         if mode == "validation" and not depth_analysis_validation:
             for i in range(len(output)):
                 output[i]["rgb"] = output[i]["rgb"].view(shape_rgb)
@@ -355,8 +365,15 @@ class DDNerfModel(GeneralMipNerfModel):
                         t_vals_0, weights_0, mus_0, sigmas_0, head["part"], near, far)
                     ret[i]["smoothed_gaussian_incell_pdf_to_plot"] = depth_analysis.gaussian_incell_pdf(
                         t_vals_0, weights_0, mus_0, smoothed_sigmas, head["spart"], near, far)
-        r_mus, r_sig, r_ssig = ops.dd_records_finish(records)
-        rec = {"mus": r_mus, "sigmas": r_sig, "smoothed_sigmas": r_ssig}
-        for i in range(2):
-            ret[i].update(rec)
+        def finish_records():
+            r_mus, r_sig, r_ssig = ops.dd_records_finish(records)
+            rec = {"mus": r_mus, "sigmas": r_sig, "smoothed_sigmas": r_ssig}
+            for i in range(2):
+                ret[i].update(rec)
+
+        deferred = getattr(self, "_deferred_records", None)
+        if deferred is not None:   # run_iter over several chunks: it collects the lengths when every chunk is in the queue
+            deferred.append(finish_records)
+        else:
+            finish_records()
         return ret

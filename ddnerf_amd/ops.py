@@ -227,12 +227,10 @@ def dd_records_launch(weights, mus, sigmas, ssig):
 def _records_slot(dev):
     """where the compaction kernel writes the records' length: one int32 of PINNED host memory (the device writes it in place --
     pinned memory is mapped into the device's address space -- so no copy is enqueued behind the kernel)"""
-    ring = _PINNED.get(str(dev))
-    if ring is None:  # (built once per device: a setdefault(...) default would allocate eight pinned tensors on every chunk)
-        ring = _PINNED[str(dev)] = {"slots": [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(8)], "next": 0}
-    host = ring["slots"][ring["next"] % 8]
-    ring["next"] += 1
-    return host
+    # a free list: a slot is taken by a launch and handed back by the finish that read it, so any number of chunks may be in flight
+    # (run_iter over a whole image enqueues all of them before it reads the first length)
+    free = _PINNED.setdefault(str(dev), [])
+    return free.pop() if free else torch.empty(1, dtype=torch.int32).pin_memory()
 
 
 def _records_ticket(outs, host):
@@ -248,6 +246,7 @@ def dd_records_finish(ticket):
     outs, host, ev, _total = ticket
     ev.synchronize()
     k = int(host[0])
+    _PINNED.setdefault(str(outs[0].device), []).append(host)
     return tuple(o[:k] for o in outs)
 
 

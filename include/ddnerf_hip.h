@@ -51,6 +51,9 @@ typedef void *ddnerf_stream_t;
 
 int ddnerf_abi_version(void);
 const char *ddnerf_error_string(int code);
+/* How this library was built: ABI version, whether it is the product or the diagnostic (clock-stamp) build, and the experiment
+ * switches the generator of the two-group bf16 kernel body ran with ("" for the product body).  Static string, never NULL. */
+const char *ddnerf_build_info(void);
 
 /* a1  GeneralMipNerfModel.get_rays_batches   models/models.py:144-162 */
 int ddnerf_pack_rays(const float *origins, const float *directions, const float *radii, float near_, float far_,

@@ -52,3 +52,44 @@ def test_render_line_has_the_contract_fields():
 def test_train_line():
     d = _bench("--mode", "train", "--mlp", "x3", "--no-cpu-baseline")
     assert d["config"]["mode"] == "train" and d["value"] > 0 and "cpu_baseline" not in d and "x3_tier" not in d
+
+
+def test_multi_rank_branch_on_a_one_rank_rccl_group():
+    """bench.py's N > 1 code path -- init_process_group("nccl", device_id=...), the barrier fences, the MAX all-reduce of the timed
+    region, the train leg with its in-backward gradient all-reduce, `rccl_ranks` / `backend` / `train` in the line -- executed on the
+    box's one GPU as a one-rank RCCL group (--single-rank-rccl), in --mode both: the first 8-GPU run must not be the first execution
+    of these lines."""
+    d = _bench("--single-rank-rccl", "--no-cpu-baseline", "--mlp", "x3")
+    assert d["rccl_ranks"] == 1 and "nccl" in d["backend"] and "RCCL" in d["backend"] and d["n_gpus"] == 1
+    assert d["config"]["mode"] == "render" and d["roofline"]["launches_timed"] == 3
+    t = d["train"]
+    assert t["value"] > 0 and t["ms_per_step"] > d["ms_per_step"] and "all-reduce" in t["collective"]
+    assert 0 < t["roofline"]["frac"] < t["roofline"]["frac_issued"] < 1.0
+
+
+def test_bf16_config_in_both_mode_reports_the_render_leg():
+    """config_ff.yml defaults to the inference-only bf16 kernel: `--mode both` (the N > 1 default) must print the render line and say
+    that there is no training leg, not exit after the render leg was measured."""
+    d = _bench("--single-rank-rccl", "--no-cpu-baseline", "--config", "config_ff.yml", "--no-clock")
+    assert d["config"]["mode"] == "render" and d["value"] > 0 and d["roofline"]["peak"] == 2500.0
+    assert "skipped" in d["train"] and "inference-only" in d["train"]["skipped"]
+
+
+def test_two_ranks_through_the_launcher_on_one_gpu():
+    """`bench.py --gpus 2` starts and supervises two ranks itself; on a one-GPU box both use GPU 0 over gloo (--share-gpu: RCCL
+    refuses two ranks on one device).  The launcher, the rendezvous, the fences and the MAX reduce across two real processes."""
+    d = _bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--rays", "1024", "--mlp", "x3")
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and "gloo" in d["backend"] and "rehearsal" in d["backend"]
+    assert d["config"]["global_rays"] == 2048 and d["config"]["rays_per_gpu"] == 1024
+    assert abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert d["train"]["value"] > 0 and "all-reduce" in d["train"]["collective"] and "cpu_baseline" not in d
+
+
+def test_image_level_number():
+    """--image HxW: one full validation image through run_iter (all its ray chunks), seconds per image beside the per-chunk
+    figure; the chunk loop must not cost the image more than a few per cent of the per-chunk rate."""
+    d = _bench("--image", "400x400", "--no-cpu-baseline", "--no-bf16-tier", "--rays", "16384")
+    im = d["image"]
+    assert im["size"] == "400x400" and im["rays"] == 160000 and im["chunks"] == 10 and im["rgb_shape"] == [400, 400, 3]
+    assert abs(im["rays_per_s"] - 160000 / im["s_per_image"]) <= 1e-2 * im["rays_per_s"]
+    assert im["rays_per_s"] >= 0.9 * d["value"], (im, d["value"])

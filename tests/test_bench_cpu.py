@@ -39,6 +39,17 @@ def test_config_workloads():
     assert (a.rays, a.scaling) == (8192, "weak")
     a = bench.parse(["--config", "config_blender_mipnerf.yml", "--gpus", "2"])
     assert (a.rays, a.mode, a.mlp) == (4096, "both", "fp32")
+    # configs[2] under the driver's N > 1 launch: the bf16 kernel, both legs asked for (bench.main prints the render leg and
+    # says that the inference-only kernel has no training leg: tests/test_bench_contract.py runs it)
+    a = bench.parse(["--config", "config_ff.yml", "--gpus", "8"])
+    assert (a.mlp, a.mode, a.rays, a.scaling) == ("bf16", "both", 4096, "weak")
+    # the one-GPU rehearsals of the N > 1 path
+    a = bench.parse(["--single-rank-rccl"])
+    assert (a.gpus, a.mode, a.backend) == (1, "both", "nccl")
+    a = bench.parse(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
+    assert a.share_gpu and a.backend == "gloo" and a.mode == "both"
+    a = bench.parse(["--image", "800x800"])
+    assert a.image == (800, 800)
 
 
 def _child(code):

@@ -54,7 +54,7 @@ def main():
     M = 524288
     L, launch, keep = setup(so, M)
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-    stamps = torch.zeros(256 * 6 + 256 * 192, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(n_cu * (6 + 192), dtype=torch.int64, device="cuda")   # (six values per workgroup, then 192 per workgroup: the grid is one workgroup per CU)
     has_stamps = hasattr(L, "ddnerf_debug_set_stamps_g2")
     if has_stamps:
         L.ddnerf_debug_set_stamps_g2.argtypes = [C.c_void_p]
@@ -78,13 +78,13 @@ def main():
         print("%s: launch %.4f ms (%.4f of peak)" % (name, ms, 1220608 * M / ms / 1e9 / 2500))
         return
     allst = stamps.cpu().numpy()
-    s = allst[:256 * 6].reshape(256, 6).astype(np.float64)[:n_cu]
+    s = allst[:n_cu * 6].reshape(n_cu, 6).astype(np.float64)
     clk = (s[:, 2] - s[:, 0]) / (s[:, 3] - s[:, 1]) * 100.0
     cyc = (s[:, 2] - s[:, 0]) / s[:, 4]
     print("%s: launch %.4f ms (%.4f of peak); clock median %.0f MHz; %.0f cycles per 512-sample tile (ideal 154240 -> pipe %.1f %% busy); loop %.1f us"
           % (name, ms, 1220608 * M / ms / 1e9 / 2500, np.median(clk), np.median(cyc), 100 * 154240 / np.median(cyc), np.median(s[:, 3] - s[:, 1]) / 100), flush=True)
     gen = load_gen()
-    allp = allst[256 * 6:].reshape(256, 192).astype(np.float64)[:n_cu]
+    allp = allst[n_cu * 6:].reshape(n_cu, 192).astype(np.float64)
     if allp[:, 1:gen.NPER + 1].any():
         ps = allp[:, :gen.NPER + 1]
         med = np.median(np.diff(ps, axis=1), axis=0)
