@@ -414,6 +414,11 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1 or args.single_rank_rccl   # (--single-rank-rccl: the N > 1 code path on a one-rank group, for one-GPU boxes)
+    # stdout carries ONE JSON line.  Native libraries write there too (RCCL prints a version banner on file descriptor 1 when the
+    # process group comes up): from here on descriptor 1 IS stderr, and the line goes out through a private copy of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     # The other tiers are measured by child runs BEFORE this process touches the GPU: a child that shares the card with an idle
     # parent context measures the launch-heavy bf16 step up to 1.6x slower than a run of its own (0.89 -> 1.39 ms).
@@ -550,7 +555,8 @@ def main(argv=None):
         line.update(tiers)
         if world == 1 and not args.no_cpu_baseline and head == "render":
             line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f)
-        print(json.dumps(line), flush=True)
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if dist:
         td.destroy_process_group()
 

@@ -29,6 +29,15 @@ _SIGS = {
     "ddnerf_mlp_bf16g2_packed_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_bf16g2_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_bf16g2_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
+    "ddnerf_mlp_f16_packed_bytes": (C.c_size_t, [C.c_int]),
+    "ddnerf_mlp_f16_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
+    "ddnerf_mlp_f16_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
+    "ddnerf_mlp_f16g1_packed_bytes": (C.c_size_t, [C.c_int]),
+    "ddnerf_mlp_f16g1_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
+    "ddnerf_mlp_f16g1_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
+    "ddnerf_mlp_f16g2_packed_bytes": (C.c_size_t, [C.c_int]),
+    "ddnerf_mlp_f16g2_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
+    "ddnerf_mlp_f16g2_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
     "ddnerf_mlp_x3_packed_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_x3_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_x3_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),

@@ -35,7 +35,7 @@ class _FusedMLP(torch.nn.Module):
         self.fc_rgb = torch.nn.Linear(128, 3)
         if self.depth_head:
             self.fc_mu_sigma = torch.nn.Linear(128, 2)
-        self.mlp_dtype = "fp32"  # "fp32": exact-fp32 MFMA kernel; "bf16": bf16-MFMA kernel
+        self.mlp_dtype = "fp32"  # "fp32": exact-fp32 MFMA kernel; "x3": bf16 MFMA on exact hi/lo splits; "bf16" / "fp16": plain 16-bit MFMA kernels
         self._flat = None
         self._flatten()
 

@@ -53,14 +53,16 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 #   touch=<file>      code-page touch: every block starts with an s_load_dword from the code address listed for it in <file> (one signed
 #                     byte offset from the s_getpc at the body's top per block; `nop` = a filler of the same size) -- see tools/g2_touch.py
 #   nodma=1 / nox=1   TIMING ONLY, results wrong: no LDS-DMA pieces / no feature fetches are issued
+#   nopf=1            the L2 prefetch touches of feature rows are not issued (results unchanged: they load into a register nothing reads)
+#   xpolicy=a_b       cache-policy bits of the feature fetches instead of `nt` (underscores for spaces; `none` = default policy)
 EXP_DEFAULT = dict(stamp_periods="0", stamp_ksteps="", sgpr_stamps="", dummy_valu="0,0", skip_fill="", skip_every="1", head_pad="0", align="0",
-                   dma_span="1/1", touch="", nodma="0", nox="0")
+                   dma_span="1/1", touch="", nodma="0", nox="0", nopf="0", xpolicy="nt")
 EXP = dict(EXP_DEFAULT)
 
 
 def set_experiment(opts):
     """install experiment switches (dict key -> string); unknown keys are an error"""
-    global STAMP_PERIODS, DUMMY_VALU, SKIP_FILL, SKIP_EVERY, HEAD_PAD, ALIGN, STAMP_KSTEPS, DMA_SPAN_NUM, DMA_SPAN_DEN, SGPR_STAMPS, TOUCH, NODMA, NOX
+    global STAMP_PERIODS, DUMMY_VALU, SKIP_FILL, SKIP_EVERY, HEAD_PAD, ALIGN, STAMP_KSTEPS, DMA_SPAN_NUM, DMA_SPAN_DEN, SGPR_STAMPS, TOUCH, NODMA, NOX, NOPF, XPOLICY
     for k in opts:
         if k not in EXP_DEFAULT:
             raise SystemExit("gen_bf16_g2: unknown experiment switch %r (known: %s)" % (k, ", ".join(sorted(EXP_DEFAULT))))
@@ -79,7 +81,8 @@ def set_experiment(opts):
     if SGPR_STAMPS:
         assert 0 <= SGPR_STAMPS[0] < SGPR_STAMPS[1] and SGPR_STAMPS[1] - SGPR_STAMPS[0] <= NSTAMP_SGPR - 1, "sgpr_stamps: at most %d blocks" % (NSTAMP_SGPR - 1)
     TOUCH = [x for x in open(EXP["touch"]).read().split()] if EXP["touch"] else None
-    NODMA, NOX = EXP["nodma"] == "1", EXP["nox"] == "1"
+    NODMA, NOX, NOPF = EXP["nodma"] == "1", EXP["nox"] == "1", EXP["nopf"] == "1"
+    XPOLICY = "" if EXP["xpolicy"] == "none" else " " + EXP["xpolicy"].replace("_", " ")
 
 
 def options_string():
@@ -312,7 +315,7 @@ class Gen:
         self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, (g * 64 + c * 16) * FEAT_ROW))
         self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
         if not NOX:
-            self.e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d nt" % (reg(kind, r, 4), V_TMP1, 64 * q))
+            self.e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d%s" % (reg(kind, r, 4), V_TMP1, 64 * q, XPOLICY))
         self.vm_issue("x", key)
 
     def prefetch(self, nxt, g, line):
@@ -321,7 +324,7 @@ class Gen:
         self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, g * 64 * FEAT_ROW))
         self.e("v_lshlrev_b32 v%d, 4, v%d" % (V_TMP1, V_LANE16))
         self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_TMP1))
-        if not NOX:
+        if not (NOX or NOPF):
             self.e("buffer_load_dword v%d, v%d, %%0, 0 offen offset:%d" % (V_PF, V_TMP1, 128 * line))
         self.vm_issue("x")
 
@@ -709,7 +712,7 @@ class Gen:
                 for (dst, g) in ((frag(1, c, 4 + q), 0), (treg(c, q), 1)):
                     e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, (g * 64 + c * 16) * FEAT_ROW))
                     e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
-                    e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d nt" % (reg(dst[0], dst[1], 4), V_TMP1, 64 * q))
+                    e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d%s" % (reg(dst[0], dst[1], 4), V_TMP1, 64 * q, XPOLICY))
         e("s_waitcnt vmcnt(0)")
         e("s_barrier")
 
@@ -788,10 +791,16 @@ if __name__ == "__main__":
     for depth_head in (0, 1):
         for stamp in (0, 1):
             g, blocks, NK = generate(depth_head, stamp)
+            text = "".join('"%s\\n"\n' % x for x in g.out)
             with open(os.path.join(outdir, "mlp_bf16_g2_body_d%d%s.gen.inc" % (depth_head, "s" if stamp else "")), "w") as f:
                 # (one string literal per line: clang locates every line of an asm string by re-lexing its token from the start, which
                 # on one megabyte-long literal takes minutes)
-                f.write("".join('"%s\\n"\n' % x for x in g.out))
+                f.write(text)
+            if not stamp:
+                # the fp16 tier (mlp_f16_g2.hip): the same body on v_mfma_f32_16x16x32_f16 with v_cvt_pk_f16_f32 re-packs -- same registers,
+                # same LDS image, same schedule; the ReLU on the packed bit patterns (v_pk_max_i16) holds for any sign-magnitude format
+                with open(os.path.join(outdir, "mlp_f16_g2_body_d%d.gen.inc" % depth_head), "w") as f:
+                    f.write(text.replace("v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16").replace("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32"))
             nlines = len(g.out)
     with open(os.path.join(outdir, "mlp_bf16_g2_tables.gen.inc"), "w") as f:
         f.write("\n".join(tables(blocks)) + "\n")

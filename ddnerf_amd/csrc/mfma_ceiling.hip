@@ -5,7 +5,7 @@
 //   mode 0: v_mfma_f32_16x16x32_bf16 back to back, operands in registers
 //   mode 1: + the A fragment of every k-step (four MFMAs) read from LDS by one ds_read_b128, three k-steps ahead (the kernels' ratio)
 //   mode 2: + the kernels' weight staging: one 1-KiB LDS-DMA piece per wave per 24 MFMAs from a 1.4 MB image (L2 hits) into four
-//           36-KiB slots, one s_barrier behind a counted s_waitcnt vmcnt per 96 MFMAs (two-group kernel: one piece per 24.8, one
+//           36-KiB slots, one s_barrier behind a counted s_waitcnt vmcnt (three barriers of lead) per 96 MFMAs (two-group kernel: one piece per 24.8, one
 //           barrier per 117)
 // Operands: uniform(-1, 1) bf16 (the caller fills `src`).  Every workgroup reports d(s_memtime), d(s_memrealtime).
 #include "mlp_bf16_common.h"
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256, 1) void mfma_ceiling_kernel(const char *__rest
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (MODE == 2) {
-            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // (the pieces of the previous iteration have landed, for every wave)
+            // (the pieces issued three iterations ago have landed, for every wave: the kernels give a chunk two to three periods between
+            // its issue and the barrier that certifies it -- a piece takes 2.5 - 3 k cycles to land when every CU streams)
+            asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");

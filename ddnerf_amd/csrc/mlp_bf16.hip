@@ -35,14 +35,22 @@
 #define M16_PLANES 1
 // (in the library this kernel is ddnerf_mlp_bf16g1_*: ddnerf_mlp_bf16_* picks between it and the two-group kernel by launch size,
 // mlp_bf16_g2.hip; a stand-alone build of this file for A/B timing exports it as ddnerf_mlp_bf16_* itself)
+// M16_HALF (mlp_f16.hip compiles this file a second time with it): the fp16 tier -- v_mfma_f32_16x16x32_f16 and v_cvt_pk_f16_f32 in place
+// of the bf16 forms, weights packed as fp16; everything else is shared.
+#ifdef M16_HALF
+#define M16_SYM(x) ddnerf_mlp_f16g1_##x
+#define M16_KERNEL mlp_f16_fwd_kernel
+#define M16_PACK_KERNEL mlp_f16_pack_kernel
+#else
 #ifdef BF16_DISPATCH
 #define M16_SYM(x) ddnerf_mlp_bf16g1_##x
 #else
 #define M16_SYM(x) ddnerf_mlp_bf16_##x
 #endif
 #define M16_KERNEL mlp_bf16_fwd_kernel
-#define M16_FEAT_T void
 #define M16_PACK_KERNEL mlp_bf16_pack_kernel
+#endif
+#define M16_FEAT_T void
 #define NSTAGE 40
 // stage -> (layer, first block, blocks); the last stage also carries the heads block
 static constexpr int kStage[NSTAGE][3] = {

@@ -9,7 +9,24 @@
 
 #include "mlp_bf16_g2_tables.gen.inc"
 
+// G2_HALF (mlp_f16_g2.hip compiles this file a second time with it): the fp16 tier -- fp16 operands (11 significant bits against
+// bf16's 8), the body generated with the f16 forms of the MFMA and the re-pack conversion; everything else is shared.
+#ifdef G2_HALF
+#define G2_SYM(x) ddnerf_mlp_f16g2_##x
+#define G2_G1_SYM(x) ddnerf_mlp_f16g1_##x
+#define G2_ANY_SYM(x) ddnerf_mlp_f16_##x
+#define G2_KERNEL mlp_f16g2_fwd_kernel
+#define G2_PACK_KERNEL mlp_f16g2_pack_kernel
+typedef _Float16 g2_elem;
+#else
+#define G2_SYM(x) ddnerf_mlp_bf16g2_##x
+#define G2_G1_SYM(x) ddnerf_mlp_bf16g1_##x
+#define G2_ANY_SYM(x) ddnerf_mlp_bf16_##x
+#define G2_KERNEL mlp_bf16g2_fwd_kernel
+#define G2_PACK_KERNEL mlp_bf16g2_pack_kernel
+typedef __bf16 g2_elem;
 extern "C" __attribute__((visibility("default"))) const char *ddnerf_bf16g2_generator_options(void) { return G2_GENERATOR_OPTIONS; }
+#endif
 
 #define G2_SLOT_BYTES (36 * 1024)
 #define G2_LDS_BYTES (4 * G2_SLOT_BYTES)
@@ -62,7 +79,7 @@ __device__ __forceinline__ float g2_srcb(const float *__restrict__ P, const G2Sr
     return 0.0f;
 }
 
-__global__ __launch_bounds__(256) void mlp_bf16g2_pack_kernel(const float *__restrict__ P, G2Src pl, unsigned short *__restrict__ packed) {
+__global__ __launch_bounds__(256) void G2_PACK_KERNEL(const float *__restrict__ P, G2Src pl, unsigned short *__restrict__ packed) {
     const int si = blockIdx.x;
     const int l = kG2Slice[si][0], K = kG2K[l], o0 = 16 * kG2Slice[si][1];
     unsigned short *dst = packed + kG2Slice[si][2] / 2;
@@ -73,7 +90,7 @@ __global__ __launch_bounds__(256) void mlp_bf16g2_pack_kernel(const float *__res
         if (r2 < plane) {
             const int row = r2 / g2_rowb(K), col = (r2 % g2_rowb(K)) / 2;
             const float v = col < K ? g2_srcw(P, pl, l, o0 + row, korder32(col)) : 0.0f;
-            w = __builtin_bit_cast(unsigned short, (__bf16)v);
+            w = __builtin_bit_cast(unsigned short, (g2_elem)v);
         } else {
             const int bi = (r2 - plane) / 4, half = ((r2 - plane) % 4) / 2;
             const unsigned u = __builtin_bit_cast(unsigned, g2_srcb(P, pl, l, o0 + bi));
@@ -83,16 +100,16 @@ __global__ __launch_bounds__(256) void mlp_bf16g2_pack_kernel(const float *__res
     }
 }
 
-DDN_EXPORT size_t ddnerf_mlp_bf16g2_packed_bytes(int depth_head) {
+DDN_EXPORT size_t G2_SYM(packed_bytes)(int depth_head) {
     (void)depth_head;
     return (size_t)G2_IMG_BYTES;
 }
-DDN_EXPORT int ddnerf_mlp_bf16g2_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
+DDN_EXPORT int G2_SYM(pack)(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
     DDN_REQUIRE(params && packed, DDNERF_E_ARG);
     DDN_REQUIRE(ddn_aligned(packed, 16), DDNERF_E_ALIGN);
     // (the chunk tails travel to LDS with their chunk and are never read: zeroed once, so that the image is a function of the parameters)
     if (hipMemsetAsync(packed, 0, (size_t)G2_IMG_BYTES, (hipStream_t)stream) != hipSuccess) return DDNERF_E_ARG;
-    hipLaunchKernelGGL(mlp_bf16g2_pack_kernel, dim3(G2_NSLICE), dim3(256), 0, (hipStream_t)stream, params, g2_make_src(depth_head),
+    hipLaunchKernelGGL(G2_PACK_KERNEL, dim3(G2_NSLICE), dim3(256), 0, (hipStream_t)stream, params, g2_make_src(depth_head),
                        (unsigned short *)packed);
     return ddn_launch_status();
 }
@@ -104,6 +121,9 @@ __device__ unsigned long long *g_bf16g2_stamps;
 DDN_EXPORT int ddnerf_debug_set_stamps_g2(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bf16g2_stamps), &p, sizeof(p)); }
 #define G2_BODY_D0 "mlp_bf16_g2_body_d0s.gen.inc"
 #define G2_BODY_D1 "mlp_bf16_g2_body_d1s.gen.inc"
+#elif defined(G2_HALF)
+#define G2_BODY_D0 "mlp_f16_g2_body_d0.gen.inc"
+#define G2_BODY_D1 "mlp_f16_g2_body_d1.gen.inc"
 #else
 #define G2_BODY_D0 "mlp_bf16_g2_body_d0.gen.inc"
 #define G2_BODY_D1 "mlp_bf16_g2_body_d1.gen.inc"
@@ -112,7 +132,7 @@ DDN_EXPORT int ddnerf_debug_set_stamps_g2(void *p) { return (int)hipMemcpyToSymb
 // Everything vector lives in the body's own registers from its first-tile prologue on (the compiler is told that the body clobbers the
 // whole vector file, and has nothing vector of its own alive across it: the loop below is scalar).
 template <bool DEPTH_HEAD>
-__global__ __launch_bounds__(256, 1) void mlp_bf16g2_fwd_kernel(const char *__restrict__ feat, const char *__restrict__ packed,
+__global__ __launch_bounds__(256, 1) void G2_KERNEL(const char *__restrict__ feat, const char *__restrict__ packed,
                                                                float *__restrict__ raw, long M, long ntiles) {
     __shared__ __attribute__((aligned(16))) char lds[G2_LDS_BYTES];
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2_fwd_kernel(const char *__re
 // (the body addresses feature rows and outputs with 32-bit byte offsets, next tile included: launches of at most this many samples)
 #define G2_MAX_LAUNCH (1L << 22)
 
-DDN_EXPORT int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream) {
+DDN_EXPORT int G2_SYM(forward)(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream) {
     DDN_REQUIRE(feat && packed && raw, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16), DDNERF_E_ALIGN);
@@ -190,9 +210,9 @@ DDN_EXPORT int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, i
         const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
         const char *f = (const char *)feat + (size_t)m0 * (2 * DDNERF_FEAT_LD);
         if (depth_head)
-            hipLaunchKernelGGL(mlp_bf16g2_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, f, (const char *)packed, raw + m0 * 6, m, ntiles);
+            hipLaunchKernelGGL(G2_KERNEL<true>, grid, dim3(256), 0, (hipStream_t)stream, f, (const char *)packed, raw + m0 * 6, m, ntiles);
         else
-            hipLaunchKernelGGL(mlp_bf16g2_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f, (const char *)packed, raw + m0 * 4, m, ntiles);
+            hipLaunchKernelGGL(G2_KERNEL<false>, grid, dim3(256), 0, (hipStream_t)stream, f, (const char *)packed, raw + m0 * 4, m, ntiles);
     }
     return ddn_launch_status();
 }
@@ -201,10 +221,10 @@ DDN_EXPORT int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, i
 // ---- ddnerf_mlp_bf16_*: ONE weight image for both bf16 kernels (the one-group image, then this kernel's), the forward picks by size.
 // Both kernels produce the same bits for the same sample (tests/test_hip_bf16_g2.py), so the choice is invisible in the results; it
 // matters for time only: a 512-sample tile per workgroup wants enough tiles to fill the chip.
-extern "C" size_t ddnerf_mlp_bf16g1_packed_bytes(int depth_head);
-extern "C" int ddnerf_mlp_bf16g1_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
-extern "C" int ddnerf_mlp_bf16g1_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
-static size_t g2_image_offset(int depth_head) { return (ddnerf_mlp_bf16g1_packed_bytes(depth_head) + 255) & ~(size_t)255; }
+extern "C" size_t G2_G1_SYM(packed_bytes)(int depth_head);
+extern "C" int G2_G1_SYM(pack)(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+extern "C" int G2_G1_SYM(forward)(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
+static size_t g2_image_offset(int depth_head) { return (G2_G1_SYM(packed_bytes)(depth_head) + 255) & ~(size_t)255; }
 // Which kernel?  Both are persistent (one workgroup per CU walks the tiles), so a launch takes ceil(tiles / CUs) rounds of one tile
 // time; a 512-sample tile of the two-group kernel takes ~1.97x a 256-sample tile of the one-group kernel (it is 1 - 2 % faster per
 // sample).  The two-group kernel runs when its rounds cost no more: always from 4 rounds on, never when its tiles would leave half
@@ -221,16 +241,16 @@ static bool g2_wanted(long M) {
     const long r2 = ((M + G2_TILE - 1) / G2_TILE + n_cu - 1) / n_cu, r1 = ((M + 255) / 256 + n_cu - 1) / n_cu;
     return M >= 65536 && 197 * r2 <= 100 * r1;
 }
-DDN_EXPORT size_t ddnerf_mlp_bf16_packed_bytes(int depth_head) { return g2_image_offset(depth_head) + (size_t)G2_IMG_BYTES; }
-DDN_EXPORT int ddnerf_mlp_bf16_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
+DDN_EXPORT size_t G2_ANY_SYM(packed_bytes)(int depth_head) { return g2_image_offset(depth_head) + (size_t)G2_IMG_BYTES; }
+DDN_EXPORT int G2_ANY_SYM(pack)(const float *params, int depth_head, void *packed, ddnerf_stream_t stream) {
     DDN_REQUIRE(params && packed, DDNERF_E_ARG);
-    const int rc = ddnerf_mlp_bf16g1_pack(params, depth_head, packed, stream);
+    const int rc = G2_G1_SYM(pack)(params, depth_head, packed, stream);
     if (rc != 0) return rc;
-    return ddnerf_mlp_bf16g2_pack(params, depth_head, (char *)packed + g2_image_offset(depth_head), stream);
+    return G2_SYM(pack)(params, depth_head, (char *)packed + g2_image_offset(depth_head), stream);
 }
-DDN_EXPORT int ddnerf_mlp_bf16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream) {
+DDN_EXPORT int G2_ANY_SYM(forward)(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream) {
     DDN_REQUIRE(feat && packed && raw, DDNERF_E_ARG);
-    if (g2_wanted(M)) return ddnerf_mlp_bf16g2_forward(feat, (const char *)packed + g2_image_offset(depth_head), depth_head, raw, M, stream);
-    return ddnerf_mlp_bf16g1_forward(feat, packed, depth_head, raw, M, stream);
+    if (g2_wanted(M)) return G2_SYM(forward)(feat, (const char *)packed + g2_image_offset(depth_head), depth_head, raw, M, stream);
+    return G2_G1_SYM(forward)(feat, packed, depth_head, raw, M, stream);
 }
 #endif

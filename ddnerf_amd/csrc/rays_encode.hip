@@ -224,12 +224,19 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
     return __builtin_bit_cast(unsigned short, b);
 }
+// 16-bit feature rows: KIND 1 = bf16, KIND 2 = fp16 (the fp16 MLP tier: 11 significant bits; |features| <= 1 and the view direction's
+// components are far inside fp16's range, tiny damped values go through its subnormals or to zero: absolute error < 6e-8)
+template <int KIND>
+__device__ __forceinline__ unsigned short f32_to_h16(float f) {
+    if constexpr (KIND == 2) return __builtin_bit_cast(unsigned short, (_Float16)f);  // round-to-nearest-even
+    else return f32_to_bf16(f);
+}
 
 #ifndef ENC_SPB
 #define ENC_SPB 32  // samples per 256-thread block (measured on the bf16 rows, fine / coarse pass: 16 -> 54 / 32 us, 32 -> 48 / 26, 64 -> 53 / 30)
 #endif
 
-template <bool BF16>
+template <int KIND>   // feature rows: 0 fp32 (natural column order), 1 bf16, 2 fp16 (both in MFMA k-order)
 __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ rays, const float *__restrict__ t_vals,
                                                      void *__restrict__ feat_, int n, int S, int cylinder) {
     __shared__ float g_mean[ENC_SPB][4];
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
                                                                        // samples of one column sit in 16 different banks)
     __shared__ __attribute__((aligned(16))) float dirv[ENC_SPB][32];   // columns 96..127 of the block's RAYS (a ray's samples share them)
     __shared__ int ray_of[ENC_SPB];                                    // sample -> its ray's row of dirv
+    constexpr bool BF16 = KIND != 0;   // (the 16-bit rows: hardware transcendentals, k-order stores)
     const size_t M = (size_t)n * S;
     const size_t m0 = (size_t)blockIdx.x * ENC_SPB;
     const int tid = threadIdx.x;
@@ -316,10 +324,10 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
                 const float *src = grp < 3 ? &row[ls][32 * grp] : &dirv[ray_of[ls]][0];
                 const float4 a = *(const float4 *)(src + 4 * g), b = *(const float4 *)(src + 16 + 4 * g);
                 uint4 v;
-                v.x = (unsigned)f32_to_bf16(a.x) | ((unsigned)f32_to_bf16(a.y) << 16);
-                v.y = (unsigned)f32_to_bf16(a.z) | ((unsigned)f32_to_bf16(a.w) << 16);
-                v.z = (unsigned)f32_to_bf16(b.x) | ((unsigned)f32_to_bf16(b.y) << 16);
-                v.w = (unsigned)f32_to_bf16(b.z) | ((unsigned)f32_to_bf16(b.w) << 16);
+                v.x = (unsigned)f32_to_h16<KIND>(a.x) | ((unsigned)f32_to_h16<KIND>(a.y) << 16);
+                v.y = (unsigned)f32_to_h16<KIND>(a.z) | ((unsigned)f32_to_h16<KIND>(a.w) << 16);
+                v.z = (unsigned)f32_to_h16<KIND>(b.x) | ((unsigned)f32_to_h16<KIND>(b.y) << 16);
+                v.w = (unsigned)f32_to_h16<KIND>(b.z) | ((unsigned)f32_to_h16<KIND>(b.w) << 16);
                 *(uint4 *)(feat + ((m0 + ls) * DDNERF_FEAT_LD + 8 * j) * 2) = v;
             }
         }
@@ -341,15 +349,15 @@ DDN_EXPORT int ddnerf_encode(const float *rays, const float *t_vals, void *feat,
     DDN_REQUIRE(rays && t_vals && feat, DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ray_shape == 0 || ray_shape == 1, DDNERF_E_RANGE);
-    DDN_REQUIRE(feat_dtype == 0 || feat_dtype == 1, DDNERF_E_RANGE);
+    DDN_REQUIRE(feat_dtype >= 0 && feat_dtype <= 2, DDNERF_E_RANGE);
     DDN_REQUIRE(ddn_aligned(feat, 16), DDNERF_E_ALIGN);
     size_t M = (size_t)n * S;
     dim3 grid((unsigned)((M + ENC_SPB - 1) / ENC_SPB));
     if (feat_dtype == 0)
-        hipLaunchKernelGGL(encode_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S,
-                           ray_shape);
+        hipLaunchKernelGGL(encode_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape);
+    else if (feat_dtype == 1)
+        hipLaunchKernelGGL(encode_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape);
     else
-        hipLaunchKernelGGL(encode_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S,
-                           ray_shape);
+        hipLaunchKernelGGL(encode_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape);
     return ddn_launch_status();
 }

@@ -46,8 +46,8 @@ def _cached_pack(net, kind, builder):
     return packed
 
 
-_PACK = {"fp32": ops.mlp_f32_pack, "x3": ops.mlp_x3_pack, "bf16": ops.mlp_bf16_pack}
-_FORWARD = {"fp32": ops.mlp_f32_forward, "x3": ops.mlp_x3_forward, "bf16": ops.mlp_bf16_forward}
+_PACK = {"fp32": ops.mlp_f32_pack, "x3": ops.mlp_x3_pack, "bf16": ops.mlp_bf16_pack, "fp16": ops.mlp_f16_pack}
+_FORWARD = {"fp32": ops.mlp_f32_forward, "x3": ops.mlp_x3_forward, "bf16": ops.mlp_bf16_forward, "fp16": ops.mlp_f16_forward}
 
 
 def _packed_weights(net):
@@ -65,8 +65,8 @@ class _MLPFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat, net, *params):
-        if net.mlp_dtype == "bf16":
-            raise NotImplementedError("training runs on the fp32 / x3 MLP kernels; the plain bf16 kernel is inference-only")
+        if net.mlp_dtype in ("bf16", "fp16"):
+            raise NotImplementedError("training runs on the fp32 / x3 MLP kernels; the plain bf16 / fp16 kernels are inference-only")
         ctx.x3 = net.mlp_dtype == "x3"
         ctx.rec = False
         packed = _packed_weights(net)
@@ -105,7 +105,7 @@ class _MLPFunction(torch.autograd.Function):
 
 
 def mlp(feat, net):
-    """feat [M,128] (fp32, or k-ordered bf16 for the bf16 kernel) -> raw [M,4|6]"""
+    """feat [M,128] (fp32, or k-ordered bf16 / fp16 for the bf16 / fp16 kernels) -> raw [M,4|6]"""
     if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
         return _MLPFunction.apply(feat, net, *net.parameters())
     return _forward_kernel(feat, net)

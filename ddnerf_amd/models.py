@@ -215,11 +215,11 @@ class GeneralMipNerfModel(torch.nn.Module):
 
     def run_network(self, ray_batch, t_vals, network, mode):
         """models/models.py:117-142: encode (K1) + fused MLP (K2); [n,S,4|6]"""
-        bf16 = network.mlp_dtype == "bf16"
+        kind = network.mlp_dtype if network.mlp_dtype in ("bf16", "fp16") else "fp32"   # (the 16-bit kernels read 16-bit k-order rows)
         shape = str(self.cfg.nerf.ray_shape)
         if shape not in ("cone", "cylinder"):
             raise AssertionError("ray_shape must be 'cone' or 'cylinder'")  # math_utils.py:28
-        feat = ops.encode(ray_batch, t_vals, cylinder=(shape == "cylinder"), bf16=bf16)
+        feat = ops.encode(ray_batch, t_vals, cylinder=(shape == "cylinder"), kind=kind)
         raw = F.mlp(feat, network)
         return raw.reshape(t_vals.shape[0], t_vals.shape[1] - 1, raw.shape[-1])
 

@@ -55,12 +55,17 @@ def sample_first_cycle(rays, t_lin, t_rand=None, lindisp=False):
     return t
 
 
-def encode(rays, t_vals, cylinder=False, bf16=False):
-    """cast_rays + integrated_pos_enc + view-dir encoding -> feat [n*S,128] (fp32 or bf16)"""
+FEAT_KINDS = {"fp32": (0, torch.float32), "bf16": (1, torch.bfloat16), "fp16": (2, torch.float16)}
+
+
+def encode(rays, t_vals, cylinder=False, bf16=False, kind=None):
+    """cast_rays + integrated_pos_enc + view-dir encoding -> feat [n*S,128]: fp32 (natural column order), or bf16 / fp16 rows in the
+    MFMA k-order of the bf16 / fp16 MLP kernels (kind "fp32" | "bf16" | "fp16"; bf16=True is kind "bf16")"""
     rays, t_vals = _f32c(rays, "rays"), _f32c(t_vals, "t_vals")
     n, S = t_vals.shape[0], t_vals.shape[1] - 1
-    feat = torch.empty((n * S, FEAT_LD), dtype=torch.bfloat16 if bf16 else torch.float32, device=rays.device)
-    _lib.check(_lib.lib().ddnerf_encode(_ptr(rays), _ptr(t_vals), _ptr(feat), n, S, int(cylinder), int(bf16), _stream()),
+    code, dtype = FEAT_KINDS[kind or ("bf16" if bf16 else "fp32")]
+    feat = torch.empty((n * S, FEAT_LD), dtype=dtype, device=rays.device)
+    _lib.check(_lib.lib().ddnerf_encode(_ptr(rays), _ptr(t_vals), _ptr(feat), n, S, int(cylinder), code, _stream()),
                "ddnerf_encode")
     return feat
 
@@ -127,8 +132,9 @@ def _bf16_variant_pack(which, params_flat, depth_head):
 
 
 def _bf16_variant_forward(which, feat, packed, depth_head):
-    if not (feat.is_cuda and feat.dtype == torch.bfloat16 and feat.is_contiguous()):
-        raise _lib.DDNerfHipError("mlp_%s_forward wants a contiguous bf16 GPU feature tensor" % which)
+    want = torch.float16 if which.startswith("f16") else torch.bfloat16
+    if not (feat.is_cuda and feat.dtype == want and feat.is_contiguous()):
+        raise _lib.DDNerfHipError("mlp_%s_forward wants a contiguous %s GPU feature tensor" % (which, want))
     M = feat.shape[0]
     raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
 
@@ -159,6 +165,32 @@ def mlp_bf16g2_pack(params_flat, depth_head):
 
 def mlp_bf16g2_forward(feat, packed, depth_head):
     return _bf16_variant_forward("bf16g2", feat, packed, depth_head)
+
+
+# The fp16 tier: the same two kernels on the fp16 forms of the MFMA and of the re-pack conversion (feat: fp16 rows in k-order, as written
+# by encode(kind="fp16")); "f16" picks between them by launch size like "bf16".
+def mlp_f16_pack(params_flat, depth_head):
+    return _bf16_variant_pack("f16", params_flat, depth_head)
+
+
+def mlp_f16_forward(feat, packed, depth_head):
+    return _bf16_variant_forward("f16", feat, packed, depth_head)
+
+
+def mlp_f16g1_pack(params_flat, depth_head):
+    return _bf16_variant_pack("f16g1", params_flat, depth_head)
+
+
+def mlp_f16g1_forward(feat, packed, depth_head):
+    return _bf16_variant_forward("f16g1", feat, packed, depth_head)
+
+
+def mlp_f16g2_pack(params_flat, depth_head):
+    return _bf16_variant_pack("f16g2", params_flat, depth_head)
+
+
+def mlp_f16g2_forward(feat, packed, depth_head):
+    return _bf16_variant_forward("f16g2", feat, packed, depth_head)
 
 
 def mlp_x3_pack(params_flat, depth_head):

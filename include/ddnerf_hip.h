@@ -74,7 +74,7 @@ int ddnerf_pack_rays_first_cycle(const float *origins, const float *directions, 
 /* a3+a4+a5  cast_rays -> integrated_pos_enc, positional_encoding(view dirs), concat
  * general_utils/math_utils.py:7-166, general_utils/nerf_helpers.py:127-171, models/models.py:124-133
  * t_vals [n,S+1] -> feat [n*S,128].  ray_shape: 0 cone, 1 cylinder.  feat_dtype: 0 fp32 (natural column
- * order), 1 bf16 (columns in MFMA k-order, see ddnerf_mlp_bf16_forward). */
+ * order), 1 bf16, 2 fp16 (both with the columns in MFMA k-order, see ddnerf_mlp_bf16_forward / ddnerf_mlp_f16_forward). */
 int ddnerf_encode(const float *rays, const float *t_vals, void *feat, int n, int S, int ray_shape, int feat_dtype,
                   ddnerf_stream_t stream);
 
@@ -109,6 +109,20 @@ int ddnerf_mlp_bf16g1_forward(const void *feat, const void *packed, int depth_he
 size_t ddnerf_mlp_bf16g2_packed_bytes(int depth_head);
 int ddnerf_mlp_bf16g2_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
+
+/* fp16-MFMA variant: the two bf16 kernels above built on v_mfma_f32_16x16x32_f16 / v_cvt_pk_f16_f32 (same rate, same registers, same
+ * images, same schedule); feat: fp16 [M,128] in the same k-order, as written by ddnerf_encode(feat_dtype=2).  fp16 keeps 11
+ * significant bits against bf16's 8 (operand rounding 8x smaller); biases, accumulation and outputs are fp32 as above.  Same
+ * dispatch between the one-group and the two-group kernel, same bits from both. */
+size_t ddnerf_mlp_f16_packed_bytes(int depth_head);
+int ddnerf_mlp_f16_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_f16_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
+size_t ddnerf_mlp_f16g1_packed_bytes(int depth_head);
+int ddnerf_mlp_f16g1_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_f16g1_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
+size_t ddnerf_mlp_f16g2_packed_bytes(int depth_head);
+int ddnerf_mlp_f16g2_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_f16g2_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
 
 /* K2 "x3": the same network on the bf16 matrix cores at fp32-class accuracy -- every fp32 weight and activation is split
  * exactly into hi + lo bf16, three MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulation: outputs within ~1e-6

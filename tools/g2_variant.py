@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--stamp", action="store_true")
     ap.add_argument("--experiment", action="append", default=[])
     ap.add_argument("--touch", type=int, default=None, metavar="LEAD_BYTES")
+    ap.add_argument("--touch-lines", type=int, default=1, help="the blocks that touch one boundary touch this many successive 64-byte lines behind it (one per block)")
     a = ap.parse_args()
     os.makedirs(LIB, exist_ok=True)
     exps = list(a.experiment)
@@ -90,10 +91,13 @@ def main():
         open(tf, "w").write("nop\n" * 308)
         so, dis = build(a.name, a.stamp, exps + ["touch=" + tf])
         addr, pc = block_addresses(dis)
-        offs = []
+        offs, seen = [], {}
         for i, x in enumerate(addr):
             p = (x + a.touch + 4095) // 4096 * 4096
-            offs.append(p - pc if p < addr[-1] else 0)
+            k = seen.get(p, 0)
+            seen[p] = k + 1
+            line = 64 * (k % a.touch_lines)
+            offs.append(p + line - pc if p < addr[-1] else line)
         open(tf, "w").write("\n".join(str(o) for o in offs) + "\n")
         so, dis = build(a.name, a.stamp, exps + ["touch=" + tf])
         addr2, pc2 = block_addresses(dis)
