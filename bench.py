@@ -34,8 +34,8 @@ if ROOT not in sys.path:
 
 FLOP_FINE = 1220608       # per sample, MipNeRFModel forward
 FLOP_COARSE_DD = 1221120  # per sample, DepthMipNeRFModel forward
-PEAK = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
-DTYPE = {"fp32": "f32", "bf16": "bf16 (f32 accumulate)", "x3": "f32 as exact hi+lo bf16 splits, 3 bf16 MFMAs per product (f32 accumulate)"}
+PEAK = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0, "fp16": 2500.0}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+DTYPE = {"fp32": "f32", "bf16": "bf16 (f32 accumulate)", "fp16": "fp16 (f32 accumulate)", "x3": "f32 as exact hi+lo bf16 splits, 3 bf16 MFMAs per product (f32 accumulate)"}
 TRAIN_DTYPE = {"fp32": "f32 forward / backward-data, weight gradients as bf16 hi+lo splits (3 MFMAs per product, f32 accumulate)",
                "x3": "f32 forward / backward-data as exact hi+lo bf16 splits (3 bf16 MFMAs per product), weight gradients from bf16-rounded "
                      "activation / delta records (1 MFMA per product); f32 accumulation throughout"}
@@ -49,7 +49,8 @@ CONFIGS = {
     "config_360_mipnerf.yml": ("real360", "fp32", 8192),
 }
 KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"],
-                  "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
+                  "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+                  "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
 
 
 def parse(argv=None):
@@ -63,7 +64,7 @@ def parse(argv=None):
     p.add_argument("--coarse", type=int, default=64)
     p.add_argument("--fine", type=int, default=128)
     p.add_argument("--mode", choices=["render", "train", "both"], default=None, help="default: render at N = 1, both at N > 1")
-    p.add_argument("--mlp", choices=["fp32", "x3", "bf16"], default=None, help="default: the config's BASELINE numerical mode")
+    p.add_argument("--mlp", choices=["fp32", "x3", "bf16", "fp16"], default=None, help="default: the config's BASELINE numerical mode")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-bf16-tier", action="store_true", help="skip the extra x3 / bf16 kernel measurements of the default run")
     p.add_argument("--cpu-rays", type=int, default=512, help="rays of the same workload timed on the CPU oracle")
@@ -90,7 +91,7 @@ def parse(argv=None):
         h, w = args.image.lower().split("x")
         args.image = (int(h), int(w))
     if args.ramp is None:
-        args.ramp = TIER_RAMP if (args.mlp in ("bf16", "x3") and args.mode == "render") else 0
+        args.ramp = TIER_RAMP if (args.mlp in ("bf16", "x3", "fp16") and args.mode == "render") else 0
     args.scaling = "strong" if args.global_rays else "weak"
     if args.global_rays:
         if args.global_rays % args.gpus:
@@ -261,7 +262,7 @@ def train_tier(args, mlp):
 def extra_tier(args, mlp):
     """The same render workload on another MLP kernel, reported beside the exact-fp32 headline, never as `value`:
     "bf16" = plain bf16 MFMA (BASELINE configs[2]'s numerical mode; the north-star roofline target is stated against the
-    bf16 MFMA peak); "x3" = bf16 MFMA with exact hi/lo operand splits (three MFMAs per product, fp32-class accuracy: it
+    bf16 MFMA peak); "fp16" = the same kernels on the fp16 forms of the instructions (11 significant bits, same rate); "x3" = bf16 MFMA with exact hi/lo operand splits (three MFMAs per product, fp32-class accuracy: it
     meets the same 1e-4 parity bar as the exact kernel) -- its roofline counts the 3x bf16 MFMA work it really issues.
     Measured by a child `bench.py --mlp <tier>` run, started before this process initialises the GPU (inside this process,
     behind the fp32 run, the launch-heavy bf16 step measures up to 4x slower; beside an idle parent context 1.6x)."""
@@ -426,6 +427,7 @@ def main(argv=None):
     if world == 1 and not dist and args.mode == "render" and args.mlp == "fp32" and args.config == "config_blender.yml" and not args.no_bf16_tier:
         tiers["x3_tier"] = extra_tier(args, "x3")
         tiers["bf16_tier"] = extra_tier(args, "bf16")
+        tiers["fp16_tier"] = extra_tier(args, "fp16")
         tiers["train_tier"] = {"fp32": train_tier(args, "fp32"), "x3": train_tier(args, "x3")}
 
     import torch
@@ -493,11 +495,11 @@ def main(argv=None):
 
         res["render"] = (timed(render_step), timer.mean_ms(M_fine))
     train_skipped = None
-    if args.mode in ("train", "both") and args.mlp == "bf16":
+    if args.mode in ("train", "both") and args.mlp in ("bf16", "fp16"):
         # there is no bf16 training tier (the reference trains in fp32; ddnerf_amd/functions.py raises)
         if args.mode == "train":
             raise SystemExit("bench.py: training runs on the fp32 / x3 MLP kernels (--mlp fp32|x3)")
-        train_skipped = "no training leg: --mlp bf16 is an inference-only kernel (training runs on --mlp fp32 | x3)"
+        train_skipped = "no training leg: --mlp %s is an inference-only kernel (training runs on --mlp fp32 | x3)" % args.mlp
     elif args.mode in ("train", "both"):
         from ddnerf_amd import train_step
 

@@ -54,15 +54,18 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 #                     byte offset from the s_getpc at the body's top per block; `nop` = a filler of the same size) -- see tools/g2_touch.py
 #   nodma=1 / nox=1   TIMING ONLY, results wrong: no LDS-DMA pieces / no feature fetches are issued
 #   nopf=1            the L2 prefetch touches of feature rows are not issued (results unchanged: they load into a register nothing reads)
+#   pfpolicy=a_b      cache-policy bits of the L2 prefetch touches (default: none)
+#   xsame=1           TIMING ONLY, results wrong: every tile fetches tile 0's feature rows (the fetches stay, their footprint goes)
+#   touchglc=1        the code-page touches bypass the scalar cache (glc)
 #   xpolicy=a_b       cache-policy bits of the feature fetches instead of `nt` (underscores for spaces; `none` = default policy)
 EXP_DEFAULT = dict(stamp_periods="0", stamp_ksteps="", sgpr_stamps="", dummy_valu="0,0", skip_fill="", skip_every="1", head_pad="0", align="0",
-                   dma_span="1/1", touch="", nodma="0", nox="0", nopf="0", xpolicy="nt")
+                   dma_span="1/1", touch="", nodma="0", nox="0", nopf="0", xpolicy="nt", pfpolicy="none", xsame="0", touchglc="0")
 EXP = dict(EXP_DEFAULT)
 
 
 def set_experiment(opts):
     """install experiment switches (dict key -> string); unknown keys are an error"""
-    global STAMP_PERIODS, DUMMY_VALU, SKIP_FILL, SKIP_EVERY, HEAD_PAD, ALIGN, STAMP_KSTEPS, DMA_SPAN_NUM, DMA_SPAN_DEN, SGPR_STAMPS, TOUCH, NODMA, NOX, NOPF, XPOLICY
+    global STAMP_PERIODS, DUMMY_VALU, SKIP_FILL, SKIP_EVERY, HEAD_PAD, ALIGN, STAMP_KSTEPS, DMA_SPAN_NUM, DMA_SPAN_DEN, SGPR_STAMPS, TOUCH, NODMA, NOX, NOPF, XPOLICY, PFPOLICY, XSAME, TOUCHGLC
     for k in opts:
         if k not in EXP_DEFAULT:
             raise SystemExit("gen_bf16_g2: unknown experiment switch %r (known: %s)" % (k, ", ".join(sorted(EXP_DEFAULT))))
@@ -83,6 +86,8 @@ def set_experiment(opts):
     TOUCH = [x for x in open(EXP["touch"]).read().split()] if EXP["touch"] else None
     NODMA, NOX, NOPF = EXP["nodma"] == "1", EXP["nox"] == "1", EXP["nopf"] == "1"
     XPOLICY = "" if EXP["xpolicy"] == "none" else " " + EXP["xpolicy"].replace("_", " ")
+    PFPOLICY = "" if EXP["pfpolicy"] == "none" else " " + EXP["pfpolicy"].replace("_", " ")
+    XSAME, TOUCHGLC = EXP["xsame"] == "1", EXP["touchglc"] == "1"
 
 
 def options_string():
@@ -325,7 +330,7 @@ class Gen:
         self.e("v_lshlrev_b32 v%d, 4, v%d" % (V_TMP1, V_LANE16))
         self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_TMP1))
         if not (NOX or NOPF):
-            self.e("buffer_load_dword v%d, v%d, %%0, 0 offen offset:%d" % (V_PF, V_TMP1, 128 * line))
+            self.e("buffer_load_dword v%d, v%d, %%0, 0 offen offset:%d%s" % (V_PF, V_TMP1, 128 * line, PFPOLICY))
         self.vm_issue("x")
 
     def dma_setup(self, img, lds, npw):
@@ -582,7 +587,7 @@ class Gen:
                     self.e("s_nop 0")
                     self.e("s_nop 0")
                 else:
-                    self.e("s_load_dword s%d, s[%d:%d], 0x%x" % (S_JUNK, S_PC, S_PC + 1, int(TOUCH[i])))
+                    self.e("s_load_dword s%d, s[%d:%d], 0x%x%s" % (S_JUNK, S_PC, S_PC + 1, int(TOUCH[i]), " glc" if TOUCHGLC else ""))
             if self.stamp and SGPR_STAMPS and SGPR_STAMPS[0] <= i <= SGPR_STAMPS[1]:
                 j = i - SGPR_STAMPS[0]
                 self.e("s_memtime s[%d:%d]" % (S_STAMP0 + 2 * j, S_STAMP0 + 2 * j + 1))
@@ -729,11 +734,17 @@ class Gen:
             self.out.append("\t.fill %d, 4, 0xbf800000" % (HEAD_PAD // 4))
             self.out.append(".Lpad%=:")
         e("s_lshl_b32 s%d, %%5, 10" % S_SWAVE)
-        e("s_lshl_b32 s%d, %%6, 17" % S_TB)           # tile * 512 rows * 256 bytes
+        if XSAME:
+            e("s_mov_b32 s%d, 0" % S_TB)
+        else:
+            e("s_lshl_b32 s%d, %%6, 17" % S_TB)           # tile * 512 rows * 256 bytes
         e("s_lshl_b32 s%d, %%5, 15" % S_T0)           # wave * 128 rows
         e("s_add_u32 s%d, s%d, s%d" % (S_TB, S_TB, S_T0))
-        e("s_lshl_b32 s%d, %%7, 17" % S_TBN)
-        e("s_add_u32 s%d, s%d, s%d" % (S_TBN, S_TBN, S_TB))
+        if XSAME:
+            e("s_mov_b32 s%d, s%d" % (S_TBN, S_TB))
+        else:
+            e("s_lshl_b32 s%d, %%7, 17" % S_TBN)
+            e("s_add_u32 s%d, s%d, s%d" % (S_TBN, S_TBN, S_TB))
         e("s_lshl_b32 s%d, %%6, 9" % S_RB)
         e("s_lshl_b32 s%d, %%5, 7" % S_T0)
         e("s_add_u32 s%d, s%d, s%d" % (S_RB, S_RB, S_T0))

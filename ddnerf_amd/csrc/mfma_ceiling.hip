@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256, 1) void mfma_ceiling_kernel(const char *__rest
     cf32x4 acc[8] = {};
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     const unsigned lane16 = 16u * lane;
-    unsigned src_k = wave, dst_k = wave;   // this wave's next piece of the image / LDS KiB it lands in (the four waves interleave, as the kernels' waves share a chunk)
+    unsigned src_k = 4 * wave, dst_k = 4 * wave;   // this wave's next 4-KiB run of the image / of LDS (the four waves interleave, as the kernels' waves share a chunk)
+    const char *p_it = src;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -42,14 +43,18 @@ __global__ __launch_bounds__(256, 1) void mfma_ceiling_kernel(const char *__rest
             // (a scalar base per iteration + an immediate per k-step: no address arithmetic beside the MFMAs)
             if constexpr (MODE >= 1) a[(s + 3) & 3] = *(const cbf16x8 *)(lds + (it & 3) * (24 * 1024) + s * 1024 + 16 * lane);
             if constexpr (MODE == 2) {
-                if (s % 6 == 0) {   // one piece per 24 MFMAs
-                    const unsigned dst = lds0 + dst_k * 1024u;
-                    const char *p = src + (size_t)src_k * 1024u;
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(lane16), "s"(p) : "memory");
-                    src_k += 4;
-                    if (src_k >= CEIL_IMG / 1024u) src_k -= CEIL_IMG / 1024u;
-                    dst_k += 4;
-                    if (dst_k >= 144u) dst_k -= 144u;
+                if (s % 6 == 0) {   // one piece per 24 MFMAs; the four pieces of an iteration share ONE (M0, source base) pair and differ in
+                                    // the immediate offset, which applies to both addresses -- the kernels' form (a piece = one instruction)
+                    if (s == 0) {
+                        const unsigned dst = lds0 + dst_k * 1024u;
+                        p_it = src + (size_t)src_k * 1024u;
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(dst) : "memory");
+                        src_k += 16;
+                        if (src_k >= CEIL_IMG / 1024u) src_k -= CEIL_IMG / 1024u;
+                        dst_k += 16;
+                        if (dst_k >= 144u) dst_k -= 144u;
+                    }
+                    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane16), "s"(p_it), "n"((s / 6) * 1024) : "memory");
                 }
             }
 #pragma unroll
