@@ -239,24 +239,37 @@ class KernelTimer:
         return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
 
 
-def child_line(args, extra):
+def child_line(args, extra, env=None):
     cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--rays", str(args.rays), "--coarse", str(args.coarse),
            "--fine", str(args.fine), "--no-cpu-baseline", "--no-bf16-tier"] + extra
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 TIER_RAMP = 40  # untimed steps in front of a tier's warm-up (see --ramp)
 
 
-def train_tier(args, mlp):
+TRAIN_TIERS = {   # name -> (--mlp, environment of the child run, what the weight gradients contract)
+    "fp32": ("fp32", {}, None),
+    "fp32_pairs": ("fp32", {"DDNERF_WGRAD": "pairs"}, "opt-in speed mode DDNERF_WGRAD=pairs: exact-f32 forward / backward-data, weight gradients from bf16-rounded "
+                                                   "row-pair records (1 MFMA per product): NOT fp32-class"),
+    "x3": ("x3", {}, None),
+    "x3_exact": ("x3", {"DDNERF_X3_WGRAD": "exact"}, "strict mode DDNERF_X3_WGRAD=exact: weight gradients from exact hi/lo-word records (3 MFMAs per product): fp32-class"),
+}
+
+
+def train_tier(args, name):
     """Training throughput (forward + backward + Adam per step) of the same workload, from a child run of
     `bench.py --mode train --mlp <mlp>`; reported beside the render headline, never as `value`."""
+    mlp, env, note = TRAIN_TIERS[name]
     try:
-        d = child_line(args, ["--mode", "train", "--mlp", mlp, "--steps", "5", "--warmup", "2", "--ramp", "5"])
+        d = child_line(args, ["--mode", "train", "--mlp", mlp, "--steps", "5", "--warmup", "2", "--ramp", "5"], env)
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
-    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "roofline": d.get("roofline")}
+    out = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "roofline": d.get("roofline")}
+    if note:
+        out["dtype"] = note
+    return out
 
 
 def extra_tier(args, mlp):
@@ -428,7 +441,7 @@ def main(argv=None):
         tiers["x3_tier"] = extra_tier(args, "x3")
         tiers["bf16_tier"] = extra_tier(args, "bf16")
         tiers["fp16_tier"] = extra_tier(args, "fp16")
-        tiers["train_tier"] = {"fp32": train_tier(args, "fp32"), "x3": train_tier(args, "x3")}
+        tiers["train_tier"] = {name: train_tier(args, name) for name in TRAIN_TIERS}
 
     import torch
 

@@ -45,6 +45,12 @@ _SIGS = {
     "ddnerf_mlp_x3_packed_t_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_x3_pack_t": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_x3_backward_data": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_mlp_x3e_packed_bytes": (C.c_size_t, [C.c_int]),
+    "ddnerf_mlp_x3e_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
+    "ddnerf_mlp_x3e_forward_train": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_mlp_x3e_packed_t_bytes": (C.c_size_t, [C.c_int]),
+    "ddnerf_mlp_x3e_pack_t": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
+    "ddnerf_mlp_x3e_backward_data": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_dd_records_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ddnerf_dd_records": (C.c_int, [c_fp] * 4 + [C.c_int, C.c_int] + [c_fp] * 5 + [c_fp]),
     "ddnerf_dd_head_workspace_floats": (C.c_size_t, [C.c_int, C.c_int]),
@@ -64,6 +70,8 @@ _SIGS = {
     "ddnerf_mlp_f32_backward_data": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_mlp_f32_forward_train_rec": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_mlp_f32_backward_data_rec": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_mlp_f32_forward_train_recp": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_mlp_f32_backward_data_recp": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_ray_bundle": (C.c_int, [C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_ndc_depth_to_regular": (C.c_int, [C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp]),

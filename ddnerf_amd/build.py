@@ -23,6 +23,7 @@ SOURCES = {
     "mlp_f32.hip": [],
     "mlp_f32_train.hip": [],
     "mlp_f32_train_rec.hip": [],
+    "mlp_f32_train_recp.hip": [],
     "mlp_f32_wgrad.hip": [],
     "mlp_x3_wgrad.hip": [],
     "mlp_x3_wgrad_packed.hip": [],
@@ -38,6 +39,9 @@ SOURCES = {
     "mlp_x3_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     "mlp_x3_fwd_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     "mlp_x3_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+    # the x3 training tier's strict mode (DDNERF_X3_WGRAD=exact): the round-2 kernels that record exact hi/lo words
+    "mlp_x3e_fwd_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+    "mlp_x3e_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
 }
 
 
@@ -45,7 +49,8 @@ SOURCES = {
 # than the wait states nobody pads (csrc/check_asm_hazards.py); a violation fails the build
 CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_bf16_g2.hip": "mlp_bf16g2_fwd_kernel", "mlp_f16.hip": "mlp_f16_fwd_kernel",
            "mlp_f16_g2.hip": "mlp_f16g2_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel",
-           "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel", "mlp_x3_bwd.hip": "mlp_x3_bwd16_kernel"}
+           "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel", "mlp_x3_bwd.hip": "mlp_x3_bwd16_kernel",
+           "mlp_x3e_fwd_train.hip": "mlp_x3e_fwd16_train_kernel", "mlp_x3e_bwd.hip": "mlp_x3e_bwd16_kernel"}
 
 
 # kernels whose tile body is one block of assembly that owns the whole vector register file from its first iteration on: the loop

@@ -326,10 +326,12 @@ class Gen:
     def prefetch(self, nxt, g, line):
         """one 128-byte line of each feature row of group g (this / next tile) into the L2 / MALL: every lane touches one row; the loaded
         word goes to a register nothing reads"""
+        if NOPF:     # (nothing is issued, so nothing enters the books of vmcnt either)
+            return
         self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, g * 64 * FEAT_ROW))
         self.e("v_lshlrev_b32 v%d, 4, v%d" % (V_TMP1, V_LANE16))
         self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_TMP1))
-        if not (NOX or NOPF):
+        if not NOX:
             self.e("buffer_load_dword v%d, v%d, %%0, 0 offen offset:%d%s" % (V_PF, V_TMP1, 128 * line, PFPOLICY))
         self.vm_issue("x")
 

@@ -132,6 +132,39 @@ DDN_EXPORT int ddnerf_mlp_f32_pack_t(const float *params, int depth_head, float 
 // (bf16 hi << 16) | bf16 lo at word index ((m >> 4) * 2560 + row) * 16 + (m & 15).  The bf16x3 weight gradients split the
 // fp32 values exactly like this anyway; recording the split lets them stream contiguous runs at 4.5 - 5 TB/s instead of
 // [feature][sample] rows at 3.  A value is > 0 iff its word is != 0.
+#if F32_REC == 2
+// Third build (mlp_f32_train_recp.hip): records of bf16 ROW PAIRS, the x3 training tier's format (include/ddnerf_hip.h,
+// ddnerf_mlp_x3_wgrad_pairs): ONE word = bf16(row 2p) | bf16(row 2p + 1) << 16 at word index ((m >> 4) * 1280 + p) * 16 + (m & 15) -- half
+// the record bytes of the hi/lo words, and weight gradients with one MFMA per product on bf16-ROUNDED operands (2.2e-3 of the
+// gradient's norm from the exact tier's): an opt-in speed mode of the fp32 tier (DDNERF_WGRAD=pairs), never its default.  Rows
+// 2k and 2k + 1 of a 32x32 accumulator tile are consecutive registers of one lane, so a pair word is one v_cvt_pk_bf16_f32.
+#define F32_NAME(x) x##_recp
+typedef __bf16 rp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ size_t rec_base(int row0, size_t col, int h) { return ((col >> 4) * (ACT_ROWS / 2) + (row0 + 4 * h) / 2) * 16 + (col & 15); }
+__device__ __forceinline__ void store_tile_t(float *__restrict__ mat, size_t, int row0, size_t col, int h, const f32x16 &v) {
+    unsigned *p = (unsigned *)mat + rec_base(row0, col, h);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const rp_f32x2 two = {v[2 * k], v[2 * k + 1]};
+        TSTORE(__builtin_bit_cast(unsigned, __builtin_convertvector(two, rp_bf16x2)), p + (tile_row(2 * k, 0) / 2) * 16);
+    }
+}
+// (the backward pass only asks whether a recorded activation is > 0: the two halves of a word travel as two "floats" whose bits are
+// the bf16 patterns)
+__device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, size_t, int row0, size_t col, int h) {
+    const unsigned *p = (const unsigned *)mat + rec_base(row0, col, h);
+    f32x16 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned w = TLOAD(p + (tile_row(2 * k, 0) / 2) * 16);
+        v[2 * k] = __builtin_bit_cast(float, w & 0xffffu);
+        v[2 * k + 1] = __builtin_bit_cast(float, w >> 16);
+    }
+    return v;
+}
+__device__ __forceinline__ bool tile_positive(float w) { return (__builtin_bit_cast(unsigned, w) & 0x7fffu) != 0u; }
+#else
 #define F32_NAME(x) x##_rec
 __device__ __forceinline__ unsigned rec_word(float x) {
     const __bf16 hi = (__bf16)x;
@@ -152,6 +185,7 @@ __device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, siz
     return v;
 }
 __device__ __forceinline__ bool tile_positive(float w) { return __builtin_bit_cast(unsigned, w) != 0u; }
+#endif
 #else
 #define F32_NAME(x) x
 __device__ __forceinline__ void store_tile_t(float *__restrict__ mat, size_t ld, int row0, size_t col, int h,

@@ -58,25 +58,43 @@ def _forward_kernel(feat, net):
     return _FORWARD[net.mlp_dtype](feat, _packed_weights(net), net.depth_head)
 
 
+def x3_wgrad_exact():
+    """DDNERF_X3_WGRAD=exact: the x3 training tier records exact hi/lo words and its weight gradients run three MFMAs per product
+    (fp32-class parameter gradients: 3e-4 of the norm against fp64 autograd) instead of the default's bf16 row pairs with one MFMA per
+    product (2.2e-3 of the norm; 7.2 ms against 9.9 ms per step at BASELINE size).  Read per call, so a test can switch it."""
+    import os
+
+    return os.environ.get("DDNERF_X3_WGRAD", "pairs") == "exact"
+
+
 class _MLPFunction(torch.autograd.Function):
-    """training forward + hand-written backward of one network.  `mlp_dtype` "fp32" runs the exact fp32-MFMA kernels;
-    "x3" the split-precision bf16-MFMA kernels (same accuracy class, ~2.5x faster), which record their activations and
-    deltas pre-split for the packed-operand weight-gradient kernel; the fp32 tier's weight gradients follow ops.WGRAD_MODE."""
+    """training forward + hand-written backward of one network.  `mlp_dtype` "fp32" runs the exact fp32-MFMA kernels (forward and
+    backward-data exact; weight gradients as bf16 hi+lo splits, three MFMAs per product: fp32-class).  "x3" runs the split-precision
+    bf16-MFMA kernels: forward and backward-data at fp32-class accuracy (three MFMAs per product on exact hi/lo splits), and weight
+    gradients that by DEFAULT contract bf16-ROUNDED activation / delta records (one MFMA per product: 2.2e-3 of the gradient's norm
+    from the fp32 tier's -- NOT the fp32 tier's accuracy class; 2.7x its speed), or with DDNERF_X3_WGRAD=exact the exact hi/lo-word
+    records (three MFMAs per product: the fp32 tier's class again, 2.0x its speed).  The fp32 tier's weight gradients follow
+    ops.WGRAD_MODE."""
 
     @staticmethod
     def forward(ctx, feat, net, *params):
         if net.mlp_dtype in ("bf16", "fp16"):
             raise NotImplementedError("training runs on the fp32 / x3 MLP kernels; the plain bf16 / fp16 kernels are inference-only")
         ctx.x3 = net.mlp_dtype == "x3"
+        ctx.x3e = ctx.x3 and x3_wgrad_exact()
         ctx.rec = False
-        packed = _packed_weights(net)
-        if ctx.x3:
-            raw, acts, bits = ops.mlp_x3_forward_train(feat, packed, net.depth_head)
+        if ctx.x3e:
+            raw, acts, bits = ops.mlp_x3e_forward_train(feat, _cached_pack(net, "x3e", ops.mlp_x3e_pack), net.depth_head)
+            ctx.save_for_backward(feat, acts, bits)
+        elif ctx.x3:
+            raw, acts, bits = ops.mlp_x3_forward_train(feat, _packed_weights(net), net.depth_head)
             ctx.save_for_backward(feat, acts, bits)
         else:
             # with the default (bf16x3) weight gradients the exact-fp32 kernels record hi/lo words for the packed-operand kernel
-            ctx.rec = ops.WGRAD_MODE == "x3"
-            raw, acts = ops.mlp_f32_forward_train(feat, packed, net.depth_head, rec=ctx.rec)
+            # DDNERF_WGRAD: "x3" (default) hi/lo-word records, three MFMAs per product: fp32-class; "pairs": bf16 row-pair records,
+            # one MFMA per product (an opt-in speed mode: bf16-rounded operands); "f32": fp32 matrices and the fp32-MFMA kernel
+            ctx.rec = {"x3": "hilo", "pairs": "pairs"}.get(ops.WGRAD_MODE, False)
+            raw, acts = ops.mlp_f32_forward_train(feat, _packed_weights(net), net.depth_head, rec=ctx.rec)
             ctx.save_for_backward(feat, acts)
         net._fwd_calls = getattr(net, "_fwd_calls", 0) + 1
         ctx.net = net
@@ -86,7 +104,10 @@ class _MLPFunction(torch.autograd.Function):
     def backward(ctx, g_raw):
         net = ctx.net
         g_raw = g_raw.contiguous()
-        if ctx.x3:
+        if ctx.x3e:
+            feat, acts, bits = ctx.saved_tensors
+            deltas = ops.mlp_x3e_backward_data(g_raw, _cached_pack(net, "x3e_t", ops.mlp_x3e_pack_t), bits, net.depth_head)
+        elif ctx.x3:
             feat, acts, bits = ctx.saved_tensors
             packed_t = _cached_pack(net, "x3_t", ops.mlp_x3_pack_t)
             deltas = ops.mlp_x3_backward_data(g_raw, packed_t, bits, net.depth_head)
@@ -96,7 +117,7 @@ class _MLPFunction(torch.autograd.Function):
             deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head, rec=ctx.rec)
         # (the x3 tier's records of bf16 row pairs and the fp32 tier's records of hi/lo words go to the record-operand weight-gradient
         # kernel; DDNERF_WGRAD=f32 keeps fp32 matrices on the fp32 tier)
-        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3h" if ctx.x3 else ("x3p" if ctx.rec else None))
+        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3p" if (ctx.x3e or ctx.rec == "hilo") else ("x3h" if (ctx.x3 or ctx.rec == "pairs") else None))
         net.last_flat_grad = flat_g  # the data-parallel bucket (ddnerf_amd.dist) reduces this buffer
         reducer = getattr(net, "grad_reducer", None)
         if reducer is not None:

@@ -473,15 +473,19 @@ def mlp_f32_pack_t(params_flat, depth_head):
     return packed
 
 
+_REC_SUFFIX = {False: "", None: "", True: "_rec", "hilo": "_rec", "pairs": "_recp"}
+
+
 def mlp_f32_forward_train(feat, packed, depth_head, rec=False):
-    """forward + recorded activations: returns raw [M,4|6], acts [2560, ld] (fp32, transposed: row = feature; rec=True: a
-    record of blocked hi/lo words instead -- x3_unsplit reads it back -- for the packed-operand weight-gradient kernel)"""
-    fn = "ddnerf_mlp_f32_forward_train" + ("_rec" if rec else "")
+    """forward + recorded activations: returns raw [M,4|6], acts [2560, ld] (fp32, transposed: row = feature).  rec=True / "hilo": a
+    record of blocked hi/lo words instead -- x3_unsplit reads it back -- for the packed-operand weight-gradient kernel; rec="pairs": a
+    record of bf16 row pairs ([1280, ld] words, x3_unpair reads it back) for the one-MFMA weight-gradient kernel"""
+    fn = "ddnerf_mlp_f32_forward_train" + _REC_SUFFIX[rec]
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
     ld = (M + 127) // 128 * 128
     raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
-    acts = _record((ACT_ROWS, ld), torch.float32, feat.device)
+    acts = _record((ACT_ROWS // 2 if rec == "pairs" else ACT_ROWS, ld), torch.float32, feat.device)
 
     def launch():
         _lib.check(getattr(_lib.lib(), fn)(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts), M, ld, _stream()), fn)
@@ -494,8 +498,8 @@ def mlp_f32_forward_train(feat, packed, depth_head, rec=False):
 
 
 def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head, rec=False):
-    """rec: `acts` is a record (mlp_f32_forward_train(rec=True)) and so is the result"""
-    fn = "ddnerf_mlp_f32_backward_data" + ("_rec" if rec else "")
+    """rec: `acts` is a record (mlp_f32_forward_train(rec=...)) and so is the result, in the same format"""
+    fn = "ddnerf_mlp_f32_backward_data" + _REC_SUFFIX[rec]
     g_raw = _f32c(g_raw, "g_raw")
     M = g_raw.shape[0]
     ld = acts.shape[1]
@@ -540,6 +544,53 @@ def mlp_x3_backward_data(g_raw, packed_t, bits, depth_head):
     deltas = _record((ACT_ROWS // 2, ld), torch.float32, g_raw.device)
     _lib.check(_lib.lib().ddnerf_mlp_x3_backward_data(_ptr(g_raw), _ptr(packed_t), _ptr(bits), int(depth_head), _ptr(deltas),
                                                       M, ld, _stream()), "ddnerf_mlp_x3_backward_data")
+    return deltas
+
+
+# ---- the x3 training tier with EXACT records (DDNERF_X3_WGRAD=exact; csrc/mlp_x3e_*.hip): the same chains, every layer's output / delta
+# recorded as blocked hi/lo words ([2560, ld]: the fp32 value's exact split) for the three-MFMA weight gradients (mode "x3p")
+def mlp_x3e_pack(params_flat, depth_head):
+    params_flat = _f32c(params_flat, "params")
+    packed = torch.empty(_lib.lib().ddnerf_mlp_x3e_packed_bytes(int(depth_head)), dtype=torch.uint8, device=params_flat.device)
+    _lib.check(_lib.lib().ddnerf_mlp_x3e_pack(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()), "ddnerf_mlp_x3e_pack")
+    return packed
+
+
+def mlp_x3e_pack_t(params_flat, depth_head):
+    params_flat = _f32c(params_flat, "params")
+    packed = torch.empty(_lib.lib().ddnerf_mlp_x3e_packed_t_bytes(int(depth_head)), dtype=torch.uint8, device=params_flat.device)
+    _lib.check(_lib.lib().ddnerf_mlp_x3e_pack_t(_ptr(params_flat), int(depth_head), _ptr(packed), _stream()), "ddnerf_mlp_x3e_pack_t")
+    return packed
+
+
+def mlp_x3e_forward_train(feat, packed, depth_head):
+    """-> raw [M,4|6], acts = a [2560, ld] record of blocked hi/lo words (x3_unsplit gives the fp32 matrix), bits [160, ld] sign words"""
+    feat = _f32c(feat, "feat")
+    M = feat.shape[0]
+    ld = (M + 127) // 128 * 128
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+    acts = _record((ACT_ROWS, ld), torch.float32, feat.device)
+    bits = _record((ACT_ROWS // 32 * 2, ld), torch.int16, feat.device)
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_mlp_x3e_forward_train(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts),
+                                                           _ptr(bits), M, ld, _stream()), "ddnerf_mlp_x3e_forward_train")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw, acts, bits
+
+
+def mlp_x3e_backward_data(g_raw, packed_t, bits, depth_head):
+    """-> deltas: a [2560, ld] record of blocked hi/lo words, like mlp_x3e_forward_train's acts"""
+    g_raw = _f32c(g_raw, "g_raw")
+    M = g_raw.shape[0]
+    ld = bits.shape[1]
+    deltas = _record((ACT_ROWS, ld), torch.float32, g_raw.device)
+    _lib.check(_lib.lib().ddnerf_mlp_x3e_backward_data(_ptr(g_raw), _ptr(packed_t), _ptr(bits), int(depth_head), _ptr(deltas),
+                                                       M, ld, _stream()), "ddnerf_mlp_x3e_backward_data")
     return deltas
 
 

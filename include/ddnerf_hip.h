@@ -150,6 +150,18 @@ size_t ddnerf_mlp_x3_packed_t_bytes(int depth_head);
 int ddnerf_mlp_x3_pack_t(const float *params, int depth_head, void *packed_t, ddnerf_stream_t stream);
 int ddnerf_mlp_x3_backward_data(const float *g_raw, const void *packed_t, const void *bits, int depth_head, float *deltas,
                                 long M, long ld, ddnerf_stream_t stream);
+/* The same two kernels with EXACT records (the strict mode of the x3 training tier): every layer's output / delta is recorded as blocked
+ * hi/lo words -- the exact split of the fp32 value, (bf16 hi << 16) | bf16 lo at word ((m >> 4) * 2560 + row) * 16 + (m & 15), the
+ * format of ddnerf_mlp_f32_forward_train's record build -- for ddnerf_mlp_x3_wgrad_packed (three MFMAs per product): fp32-class
+ * parameter gradients at twice the record bytes.  Own weight images.  acts / deltas: 2560 x ld words. */
+size_t ddnerf_mlp_x3e_packed_bytes(int depth_head);
+int ddnerf_mlp_x3e_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
+int ddnerf_mlp_x3e_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts, void *bits,
+                                 long M, long ld, ddnerf_stream_t stream);
+size_t ddnerf_mlp_x3e_packed_t_bytes(int depth_head);
+int ddnerf_mlp_x3e_pack_t(const float *params, int depth_head, void *packed_t, ddnerf_stream_t stream);
+int ddnerf_mlp_x3e_backward_data(const float *g_raw, const void *packed_t, const void *bits, int depth_head, float *deltas,
+                                 long M, long ld, ddnerf_stream_t stream);
 
 /* a8  DD head, inline in DDNerfModel.predict  models/models.py:242-260, 266-273
  * raw6 [n,nc,6] -> mus, sigmas, left_tail, part_inside (raw sigma) and smoothed sigma/left/part, all [n,nc];
@@ -288,6 +300,13 @@ int ddnerf_mlp_f32_forward_train_rec(const float *feat, const float *packed, int
                                  long ld, ddnerf_stream_t stream);
 int ddnerf_mlp_f32_backward_data_rec(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
                                  float *deltas, long M, long ld, ddnerf_stream_t stream);
+/* ... and with records of bf16 ROW PAIRS (the x3 training tier's format, see ddnerf_mlp_x3_wgrad_pairs: 1280 pair rows x ld words): the
+ * exact-fp32 forward / backward-data arithmetic again, half the record bytes, weight gradients with one MFMA per product on bf16-rounded
+ * operands -- an opt-in speed mode of the fp32 tier (DDNERF_WGRAD=pairs), not fp32-class. */
+int ddnerf_mlp_f32_forward_train_recp(const float *feat, const float *packed, int depth_head, float *raw, float *acts, long M,
+                                  long ld, ddnerf_stream_t stream);
+int ddnerf_mlp_f32_backward_data_recp(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
+                                  float *deltas, long M, long ld, ddnerf_stream_t stream);
 size_t ddnerf_mlp_f32_wgrad_workspace_floats(long M);
 int ddnerf_mlp_f32_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,
                          long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,

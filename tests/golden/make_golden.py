@@ -693,7 +693,18 @@ def gen_grad4096():
         del out, loss, model
 
 
+def gen_train1500():
+    """1500 iterations of the reference's training loop with the schedule train_model.py hard-wires (:101-107: log-lerp 5e-4 -> 5e-6 over
+    cfg.experiment.train_iters with the 2500-step x0.01 warm-up), i.e. the FIRST 1500 steps of a real run, DDNerfModel, 256 fresh rays per
+    iteration; loss / MSE / dp every 25 iterations."""
+    _gen_train(1500, 2500, None, 25, ("DDNerfModel",), "train1500")
+
+
 def gen_train300():
+    _gen_train(300, 50, 300, 10, ("DDNerfModel", "GeneralMipNerfModel"), "train300")
+
+
+def _gen_train(iters, delay, max_steps, every, model_types, tag):
     """Training parity (SURVEY.md 8d "PSNR vs ref (2)"): 300 iterations of the reference's loop (train_model.py:132-177: smoothing
     schedule, lr schedule, run_iter, loss assembly, backward, one Adam per network) on a procedural scene -- a fresh seeded batch of
     256 rays per iteration with analytic colour targets -- with perturb / noise off (no random tensors).  The learning-rate
@@ -701,8 +712,8 @@ def gen_train300():
     hard-wires (a 300-step run would otherwise never leave the warm-up).  Loss / MSE every 10 iterations."""
     import functools
 
-    n, nc, nf, iters = 256, 64, 128, 300
-    for model_type, kind in (("DDNerfModel", "blender"), ("GeneralMipNerfModel", "blender")):
+    n, nc, nf = 256, 64, 128
+    for model_type, kind in [(m, "blender") for m in model_types]:
         dd = model_type == "DDNerfModel"
         cfg = load_cfg((CFG_OF if dd else CFG_MIP_OF)[kind], nc, nf, kind)
         for mode in ("train", "validation"):
@@ -715,8 +726,9 @@ def gen_train300():
         optims = [torch.optim.Adam(model.coarse.parameters(), lr=cfg.optimizer.lr)]
         if dd:
             optims.append(torch.optim.Adam(model.fine.parameters(), lr=cfg.optimizer.lr))
-        lr_function = functools.partial(ref_helpers.learning_rate_decay, lr_init=0.0005, lr_final=5e-6, max_steps=iters,
-                                        lr_delay_steps=50, lr_delay_mult=0.01)
+        steps = max_steps if max_steps is not None else int(cfg.experiment.train_iters)       # train_model.py:102 (the config's run length)
+        lr_function = functools.partial(ref_helpers.learning_rate_decay, lr_init=0.0005, lr_final=5e-6, max_steps=steps,
+                                        lr_delay_steps=delay, lr_delay_mult=0.01)
         dsmooth = (cfg.train_params.gaussian_smooth_factor - cfg.train_params.final_smooth) / cfg.train_params.finnish_smooth
         initial_smooth = cfg.train_params.gaussian_smooth_factor
         if cfg.train_params.set_automatic_dist_reg_coeficient:
@@ -742,15 +754,15 @@ def gen_train300():
             for o in optims:
                 o.step()
                 o.zero_grad()
-            if i % 10 == 0 or i == iters - 1:
+            if i % every == 0 or i == iters - 1:
                 rec["it"].append(i)
                 rec["loss"].append(float(loss))
                 rec["mse"].append([float(m) for m in mses])
                 rec["dp"].append(float(dp))
                 rec["lr"].append(float(lr_new))
                 print(model_type, i, float(loss), [float(m) for m in mses], flush=True)
-        save("train300_%s_%s" % ("dd" if dd else "mip", kind),
-             meta=np.array([n, nc, nf, iters, 50, float(cfg.dataset.near), float(cfg.dataset.far)]),
+        save("%s_%s_%s" % (tag, "dd" if dd else "mip", kind),
+             meta=np.array([n, nc, nf, iters, delay, float(cfg.dataset.near), float(cfg.dataset.far), steps]),
              it=np.array(rec["it"]), loss=np.array(rec["loss"]), mse=np.array(rec["mse"]), dp=np.array(rec["dp"]), lr=np.array(rec["lr"]))
 
 

@@ -79,17 +79,20 @@ def test_encoder_fp16_rows(ops):
 
 
 @pytest.mark.parametrize("name", fullsize_names())
-def test_full_size_fp16_tier(name):
-    """fp16-MFMA MLP at BASELINE sizes against the reference's fp32 outputs (configs 1-5)"""
+def test_full_size_fp16_tier_meets_the_fp32_parity_bar(name):
+    """fp16-MFMA MLP at BASELINE sizes (configs 1-5) against the reference's fp32 outputs: held to the SAME absolute 1e-4 bar on RGB /
+    depth / acc / weights as the exact-fp32 and the x3 kernels (north_star: "RGB/depth within 1e-4 fp32").  Measured (tools/tier_errors.py):
+    RGB <= 1.9e-5, depth <= 7.1e-5, acc <= 2.6e-5, weights <= 1.3e-5 over the five fixtures; the bf16 kernel: 2.3e-4 / 7.8e-4."""
     from test_hip_fullsize import _run
+    from _cases import maxerr
 
     c = load_fullsize(name)
     g, st = c["g"], c["stride"]
     out = _run(c, "fp16")
     for lvl in (0, 1):
+        for k in ("rgb", "depth", "acc", "weights"):
+            e = maxerr(out[lvl][k][::st].cpu().numpy(), g["o%d_%s" % (lvl, k)])
+            assert e <= 1e-4, (name, lvl, k, e)
         rgb, ref = out[lvl]["rgb"][::st].cpu().numpy(), g["o%d_rgb" % lvl]
         psnr = -10.0 * np.log10(max(float(np.mean((rgb - ref) ** 2)), 1e-20))
-        assert psnr >= 90.0, (lvl, psnr)
-        assert np.abs(rgb - ref).max() <= 2e-4, (lvl, np.abs(rgb - ref).max())
-        depth, dref = out[lvl]["depth"][::st].cpu().numpy(), g["o%d_depth" % lvl]
-        assert np.abs(depth - dref).max() <= 5e-4 * max(1.0, np.abs(dref).max()), lvl
+        assert psnr >= 100.0, (lvl, psnr)
