@@ -287,6 +287,22 @@ def extra_tier(args, mlp):
     return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "ramp_steps": TIER_RAMP, "roofline": roof}
 
 
+def image_tier(args, mlp, size="800x800"):
+    """seconds per full validation image (all its 16384-ray chunks through run_iter) on one MLP kernel, beside the rate of ONE such chunk
+    measured in the same child run"""
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--rays", "16384", "--coarse", str(args.coarse), "--fine", str(args.fine),
+               "--no-cpu-baseline", "--no-bf16-tier", "--no-clock", "--mlp", mlp, "--image", size, "--steps", "5", "--warmup", "2"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    im = d["image"]
+    im["chunk_rays_per_s"] = d["value"]
+    im["image_over_chunk_rate"] = round(im["rays_per_s"] / d["value"], 4)
+    return im
+
+
 def cpu_baseline(args, cfg, sd_c, sd_f):
     """The CPU oracle (a C port of the reference path, oracle/) on a bounded sample of the same workload."""
     import numpy as np
@@ -442,6 +458,8 @@ def main(argv=None):
         tiers["bf16_tier"] = extra_tier(args, "bf16")
         tiers["fp16_tier"] = extra_tier(args, "fp16")
         tiers["train_tier"] = {name: train_tier(args, name) for name in TRAIN_TIERS}
+        if not args.image:     # the product-level figure (eval_nerf.py:103-111 times one whole validation image), from child runs
+            tiers["image"] = {mlp: image_tier(args, mlp) for mlp in ("fp32", "fp16", "bf16")}
 
     import torch
 

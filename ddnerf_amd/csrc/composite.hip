@@ -1,6 +1,7 @@
 // K3: alpha compositing (exclusive product scan along the ray) and the DD head.
 // Compiled with -ffp-contract=off so that every product/sum rounds like the reference's ATen CPU ops.
 #include "common.h"
+#include "sampler_device.h"
 
 // ---------------------------------------------------------------------------------------------------
 // a10  volume_render_radiance_field  general_utils/volume_rendering_utils.py:6-85
@@ -25,25 +26,38 @@ struct HeadOut {
     int *rec_counts;
     float smooth;
 };
+// HEAD + samples != nullptr: the launch also draws the fine pass's fenceposts of its rays (sample_pdf_with_mu_sigma,
+// models/samplers.py:124-215, called at models/models.py:227-237 with exactly what this kernel has just computed: the returned weights, the
+// head's mus and its SMOOTHED sigmas / part-inside / left tails) -- dd_sample_row of sampler_device.h, the stand-alone sampler kernel's
+// code, fed from LDS instead of from the arrays this kernel also writes to memory.  One launch and five [n, nc] reads less per chunk.
+struct SampleArgs {
+    const float *u_base, *rnd;
+    float *samples;
+    float div, near_, far_;
+    int ns, npad, pdf_padding;
+};
 
 template <bool HEAD>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float *__restrict__ raw, int ldr, const float *__restrict__ t_vals, const float *__restrict__ rays,
     const float *__restrict__ noise, const float *__restrict__ mus, int n, int S, int flags,
     float *__restrict__ rgb_map, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
-    float *__restrict__ depth, float *__restrict__ cdisp, float *__restrict__ rgb_out, int *__restrict__ keep_out, HeadOut ho) {
+    float *__restrict__ depth, float *__restrict__ cdisp, float *__restrict__ rgb_out, int *__restrict__ keep_out, HeadOut ho,
+    SampleArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ray = blockIdx.x * COMP_WAVES + wave;
     const bool live = ray < n;
-    constexpr int NARR = HEAD ? 9 : 8;
-    float *alpha = smem + (size_t)wave * NARR * S;  // [S]
+    constexpr int NARR = HEAD ? 12 : 8;
+    const int per_wave = NARR * S + ((HEAD && sa.samples) ? 2 * S + 2 + sa.npad : 0);
+    float *alpha = smem + (size_t)wave * per_wave;  // [S]
     float *trans = alpha + S;                    // [S]  (1-alpha+1e-10), then exclusive transmittance
     float *wpre = trans + S;                     // [S]  weights before the blender epsilon
     float *wpost = wpre + S;                     // [S]  returned weights
     float *tmp = wpost + S;                      // [S]
     float *rgbs = tmp + S;                       // [3S]
     float *musl = rgbs + 3 * S;                  // [S]  HEAD: the head's mus of this ray
+    float *ssigl = musl + S, *spartl = ssigl + S, *sleftl = spartl + S;   // [S] each, HEAD: the smoothed head values (the sampler's inputs)
     const bool white = flags & DDNERF_COMP_WHITE_BKGD, blender = flags & DDNERF_COMP_BLENDER;
     const float *t = t_vals + (size_t)(live ? ray : 0) * (S + 1);
 
@@ -78,9 +92,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
                 ho.part[m] = ddn_norm_cdf((1.0f - mu) / sg) - l;
                 const float ss = sg * ho.smooth;
                 ho.ssig[m] = ss;
+                ssigl[j] = ss;
                 const float sl = ddn_norm_cdf((0.0f - mu) / ss);
                 ho.sleft[m] = sl;
-                ho.spart[m] = ddn_norm_cdf((1.0f - mu) / ss) - sl;
+                sleftl[j] = sl;
+                const float sp = ddn_norm_cdf((1.0f - mu) / ss) - sl;
+                ho.spart[m] = sp;
+                spartl[j] = sp;
             }
         }
     }
@@ -175,6 +193,15 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             if (keep_out) keep_out[ray] = (flags & DDNERF_COMP_DP_FILTER) ? (wsum > 1e-10f ? 1 : 0) : 1;
         }
     }
+    if constexpr (HEAD) {
+        if (sa.samples) {   // the fine fenceposts of this ray (the arrays read here were last written before the wave syncs above)
+            ddn_wave_sync();
+            float *wp = alpha + NARR * S, *cdf = wp + S, *out = cdf + S + 2;
+            const size_t r = live ? ray : 0;
+            dd_sample_row(wpost, t, musl, ssigl, spartl, sleftl, sa.u_base, sa.rnd ? sa.rnd + r * sa.ns : nullptr, sa.div, sa.near_, sa.far_,
+                          sa.samples + r * sa.ns, (int32_t *)nullptr, S, sa.ns, sa.npad, sa.pdf_padding, wp, cdf, out, lane, live);
+        }
+    }
 }
 
 DDN_EXPORT int ddnerf_composite_forward(const float *raw, int ldr, const float *t_vals, const float *rays,
@@ -188,7 +215,7 @@ DDN_EXPORT int ddnerf_composite_forward(const float *raw, int ldr, const float *
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);  // S <= 512
     hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds,
                        (hipStream_t)stream, raw, ldr, t_vals, rays, noise, mus, n, S, flags, rgb_map, disp, acc,
-                       weights, depth, cdisp, rgb, (int *)nullptr, HeadOut{});
+                       weights, depth, cdisp, rgb, (int *)nullptr, HeadOut{}, SampleArgs{});
     return ddn_launch_status();
 }
 
@@ -204,7 +231,7 @@ DDN_EXPORT int ddnerf_composite_forward_keep(const float *raw, int ldr, const fl
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
     hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds, (hipStream_t)stream, raw, ldr,
                        t_vals, rays, noise, mus, n, S, flags, rgb_map, disp, acc, weights, depth, cdisp, (float *)nullptr,
-                       (int *)dp_workspace, HeadOut{});
+                       (int *)dp_workspace, HeadOut{}, SampleArgs{});
     return ddn_launch_status();
 }
 
@@ -555,15 +582,28 @@ DDN_EXPORT size_t ddnerf_dd_coarse_workspace_bytes(int n, int nc) {
     return ddnerf_dd_records_workspace_bytes(n, nc) + 16 + 2 * sizeof(float) * (size_t)((n + COMP_WAVES - 1) / COMP_WAVES);
 }
 
-DDN_EXPORT int ddnerf_dd_coarse_forward(const float *raw6, const float *t_vals, const float *rays, const float *noise, int n, int nc,
-                                        int flags, float smooth, float dist_reg, float *mus, float *sigmas, float *left,
-                                        float *part, float *ssig, float *sleft, float *spart, float *scal, float *rgb_map,
-                                        float *disp, float *acc, float *weights, float *depth, float *cdisp, float *rec_mus,
-                                        float *rec_sigmas, float *rec_ssig, int *rec_total, void *workspace, ddnerf_stream_t stream) {
+// ... and with samples != NULL also the fine pass's fenceposts [n, ns] (ddnerf_sample_pdf_mu_sigma's arguments u_base [ns], rnd [n, ns] or
+// NULL, near_, far_, pdf_padding; bit for bit that entry point's output on this launch's weights / mus / smoothed head values).
+DDN_EXPORT int ddnerf_dd_coarse_sample_forward(const float *raw6, const float *t_vals, const float *rays, const float *noise, int n, int nc,
+                                               int flags, float smooth, float dist_reg, float *mus, float *sigmas, float *left,
+                                               float *part, float *ssig, float *sleft, float *spart, float *scal, float *rgb_map,
+                                               float *disp, float *acc, float *weights, float *depth, float *cdisp, float *rec_mus,
+                                               float *rec_sigmas, float *rec_ssig, int *rec_total, void *workspace, const float *u_base,
+                                               const float *rnd, float near_, float far_, float *samples, int ns, int pdf_padding,
+                                               ddnerf_stream_t stream) {
     DDN_REQUIRE(raw6 && t_vals && rays && mus && sigmas && left && part && ssig && sleft && spart && scal, DDNERF_E_ARG);
     DDN_REQUIRE(rgb_map && disp && acc && weights && depth && cdisp && rec_mus && rec_sigmas && rec_ssig && rec_total && workspace, DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
-    size_t lds = (size_t)COMP_WAVES * 9 * nc * sizeof(float);
+    SampleArgs sa{};
+    size_t per_wave = (size_t)12 * nc;
+    if (samples) {
+        DDN_REQUIRE(u_base && ns > 1, DDNERF_E_ARG);
+        int npad = 2;
+        while (npad < ns) npad <<= 1;
+        sa = SampleArgs{u_base, rnd, samples, (float)((double)ns + 1e-5), near_, far_, ns, npad, pdf_padding};
+        per_wave += (size_t)2 * nc + 2 + npad;
+    }
+    const size_t lds = (size_t)COMP_WAVES * per_wave * sizeof(float);
     DDN_REQUIRE(lds <= 60 * 1024, DDNERF_E_RANGE);
     hipStream_t st = (hipStream_t)stream;
     int *counts = (int *)workspace, *offsets = counts + n;
@@ -572,8 +612,18 @@ DDN_EXPORT int ddnerf_dd_coarse_forward(const float *raw6, const float *t_vals, 
     float *partials = (float *)(((size_t)(rflags + (size_t)n * nc) + 15) & ~(size_t)15);
     HeadOut ho = {mus, sigmas, left, part, ssig, sleft, spart, partials, rflags, counts, smooth};
     hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(nblocks), dim3(256), lds, st, raw6, 6, t_vals, rays, noise, (const float *)nullptr, n,
-                       nc, flags, rgb_map, disp, acc, weights, depth, cdisp, (float *)nullptr, (int *)nullptr, ho);
+                       nc, flags, rgb_map, disp, acc, weights, depth, cdisp, (float *)nullptr, (int *)nullptr, ho, sa);
     hipLaunchKernelGGL(dd_records_write_kernel, dim3((unsigned)((n + 3) / 4 + 1)), dim3(256), 0, st, rflags, counts, mus, sigmas, ssig, n, nc,
                        rec_mus, rec_sigmas, rec_ssig, rec_total, partials, nblocks, dist_reg, scal);
     return ddn_launch_status();
+}
+
+DDN_EXPORT int ddnerf_dd_coarse_forward(const float *raw6, const float *t_vals, const float *rays, const float *noise, int n, int nc,
+                                        int flags, float smooth, float dist_reg, float *mus, float *sigmas, float *left,
+                                        float *part, float *ssig, float *sleft, float *spart, float *scal, float *rgb_map,
+                                        float *disp, float *acc, float *weights, float *depth, float *cdisp, float *rec_mus,
+                                        float *rec_sigmas, float *rec_ssig, int *rec_total, void *workspace, ddnerf_stream_t stream) {
+    return ddnerf_dd_coarse_sample_forward(raw6, t_vals, rays, noise, n, nc, flags, smooth, dist_reg, mus, sigmas, left, part, ssig, sleft, spart, scal,
+                                           rgb_map, disp, acc, weights, depth, cdisp, rec_mus, rec_sigmas, rec_ssig, rec_total, workspace,
+                                           (const float *)nullptr, (const float *)nullptr, 0.0f, 0.0f, (float *)nullptr, 0, 0, stream);
 }

@@ -280,22 +280,25 @@ class DDNerfModel(GeneralMipNerfModel):
         # source in the parity tests does not and is asked level by level, in the reference's draw order)
         pair = getattr(self.rng, "randn_scaled_pair", None)
         noise_pair = None
+        t_vals_1 = None
         if FUSE_RENDER and pair is not None and mc.radiance_field_noise_std > 0.0:
             noise_pair = pair(n, mc.num_coarse, mc.num_fine, dev, mc.radiance_field_noise_std)
         for i in range(2):
             if i == 1:
                 model = self.fine
                 mus = None
+            def resampling_draw():   # models/samplers.py:155-171: the u grid of the fine pass (and, with perturb, its jitter draw)
+                ns = mc.num_fine + 1
+                if mc.perturb == 0.0:
+                    return _host_const("linspace", 0.0, 0.9999, ns, dev), None
+                return _host_const("arange", 1 / (ns - 1), 0.0, ns, dev), self.rng.rand((n, ns), dev)
+
             if i == 0:
                 t_vals = self._first_cycle(ray_batch, mode)
+            elif t_vals_1 is not None:   # (the coarse pass's fused launch drew them already)
+                t_vals = t_vals_1
             else:
-                ns = mc.num_fine + 1
-                det = (mc.perturb == 0.0)
-                if det:
-                    u_base, rnd = _host_const("linspace", 0.0, 0.9999, ns, dev), None
-                else:
-                    u_base = _host_const("arange", 1 / (ns - 1), 0.0, ns, dev)
-                    rnd = self.rng.rand((n, ns), dev)
+                u_base, rnd = resampling_draw()
                 # a fresh leaf in the reference (nn.Parameter): nothing flows back through the sampler
                 t_vals = ops.sample_pdf_mu_sigma(t_vals_0, weights_0.detach(), mus_0.detach(), head["ssig"].detach(),
                                                  head["spart"].detach(), head["sleft"].detach(), u_base, rnd,
@@ -311,8 +314,13 @@ class DDNerfModel(GeneralMipNerfModel):
             fused = FUSE_RENDER and not (torch.is_grad_enabled() and raw.requires_grad)
             dp_ws = None
             if i == 0 and fused:
-                c, head, records = ops.dd_coarse_forward(raw, t_vals, ray_batch, noise, cfg.train_params.gaussian_smooth_factor,
-                                                         cfg.train_params.dist_reg_coeficient, bool(mc.white_background), blender)
+                # ... and the fine pass's fenceposts in the same launch (the resampling jitter is drawn here, behind the coarse noise and
+                # ahead of the fine noise: the reference's draw order)
+                u_base, rnd = resampling_draw()
+                c, head, records, t_vals_1 = ops.dd_coarse_forward(
+                    raw, t_vals, ray_batch, noise, cfg.train_params.gaussian_smooth_factor, cfg.train_params.dist_reg_coeficient,
+                    bool(mc.white_background), blender,
+                    sample=(u_base, rnd, cfg.dataset.near, cfg.dataset.far, bool(cfg.train_params.pdf_padding)))
             elif i == 0:
                 head = F.dd_head(raw, cfg.train_params.gaussian_smooth_factor, cfg.train_params.dist_reg_coeficient)
             if i == 0:

@@ -318,9 +318,11 @@ def pack_rays_first_cycle(ray_origins, ray_directions, ray_rad, near, far, t_lin
     return rays, t_vals
 
 
-def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, blender):
+def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, blender, sample=None):
     """The coarse pass of DDNerfModel behind the MLP, render path (models/models.py:242-295), in two launches: DD head + compositing
-    + level-0 records.  -> (composite dict, head dict, records ticket for dd_records_finish)"""
+    + level-0 records.  -> (composite dict, head dict, records ticket for dd_records_finish).  sample = (u_base [ns], rnd [n,ns] | None,
+    near, far, pdf_padding): the first launch also draws the fine pass's fenceposts (sample_pdf_mu_sigma on this pass's weights, mus and
+    smoothed head values, bit for bit) -> a fourth result, samples [n, ns]."""
     raw6, t_vals, rays, noise = _f32c(raw6, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays"), _f32c(noise, "noise")
     n, nc, ldr = raw6.shape
     assert ldr == 6
@@ -333,12 +335,23 @@ def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, b
     total = _records_slot(dev)
     ws = torch.empty(_lib.lib().ddnerf_dd_coarse_workspace_bytes(n, nc), dtype=torch.uint8, device=dev)
     flags = (1 if white_bkgd else 0) | (2 if blender else 0)
-    _lib.check(_lib.lib().ddnerf_dd_coarse_forward(
+    if sample is None:
+        u_base = rnd = samples = None
+        near_ = far_ = 0.0
+        ns = pad = 0
+    else:
+        u_base, rnd, near_, far_, pad = sample
+        u_base, rnd = _f32c(u_base, "u_base"), _f32c(rnd, "rnd")
+        ns = u_base.shape[0]
+        samples = e(n, ns)
+    _lib.check(_lib.lib().ddnerf_dd_coarse_sample_forward(
         _ptr(raw6), _ptr(t_vals), _ptr(rays), _ptr(noise), n, nc, flags, float(smooth), float(dist_reg),
         *[_ptr(head[k]) for k in ("mus", "sigmas", "left", "part", "ssig", "sleft", "spart", "scal")],
         *[_ptr(c[k]) for k in ("rgb_map", "disp", "acc", "weights", "depth", "cdisp")], *[_ptr(o) for o in outs], _ptr(total), _ptr(ws),
-        _stream()), "ddnerf_dd_coarse_forward")
-    return c, head, _records_ticket(outs, total)
+        _ptr(u_base), _ptr(rnd), float(near_), float(far_), _ptr(samples), int(ns), int(bool(pad)), _stream()), "ddnerf_dd_coarse_sample_forward")
+    if sample is None:
+        return c, head, _records_ticket(outs, total)
+    return c, head, _records_ticket(outs, total), samples
 
 
 def composite_forward_keep(raw, t_vals, rays, noise, mus, white_bkgd, blender, dp_filter):

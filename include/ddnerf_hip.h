@@ -259,6 +259,16 @@ int ddnerf_dd_coarse_forward(const float *raw6, const float *t_vals, const float
                              float *sleft, float *spart, float *scal, float *rgb_map, float *disp, float *acc, float *weights,
                              float *depth, float *cdisp, float *rec_mus, float *rec_sigmas, float *rec_ssig, int *rec_total,
                              void *workspace, ddnerf_stream_t stream);
+/* ... and with the fine pass's fenceposts drawn in the SAME first launch (samples != NULL): sample_pdf_with_mu_sigma (models/samplers.py:124-215,
+ * called at models/models.py:227-237 with this pass's returned weights, the head's mus and its smoothed sigmas / part-inside / left tails),
+ * i.e. ddnerf_sample_pdf_mu_sigma's u_base [ns], rnd [n,ns] or NULL, near_, far_, pdf_padding -> samples [n,ns], bit for bit that entry
+ * point's output.  samples == NULL: ddnerf_dd_coarse_forward. */
+int ddnerf_dd_coarse_sample_forward(const float *raw6, const float *t_vals, const float *rays, const float *noise, int n, int nc, int flags,
+                                    float smooth, float dist_reg, float *mus, float *sigmas, float *left, float *part, float *ssig,
+                                    float *sleft, float *spart, float *scal, float *rgb_map, float *disp, float *acc, float *weights,
+                                    float *depth, float *cdisp, float *rec_mus, float *rec_sigmas, float *rec_ssig, int *rec_total,
+                                    void *workspace, const float *u_base, const float *rnd, float near_, float far_, float *samples, int ns,
+                                    int pdf_padding, ddnerf_stream_t stream);
 /* The fine pass: compositing + the dp loss's row filter (models/dd_utils.py:16: torch.sum(w1) > 1e-10 IS the compositing's
  * weight sum) in one launch; dp_workspace = a ddnerf_dp_loss_workspace_bytes(n) buffer, then handed to
  * ddnerf_dp_loss_forward_kept, which is ddnerf_dp_loss_forward without its first launch. */

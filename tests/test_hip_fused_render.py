@@ -2,6 +2,7 @@
 outputs (bit for bit, except the two L2 regularisers at nc != 64, whose partial sums are grouped differently).
   ops.pack_rays_first_cycle  = pack_rays + sample_first_cycle                      (models/models.py:144-162, models/samplers.py:30-62)
   ops.dd_coarse_forward      = dd_head + composite_forward + dd_records            (models/models.py:242-295)
+  ops.dd_coarse_forward(sample=...) = ... + sample_pdf_mu_sigma in the same launch  (models/models.py:227-237, models/samplers.py:124-215)
   ops.composite_forward_keep + dp_loss_forward_kept = composite_forward + dp_loss_forward   (models/dd_utils.py:16)"""
 import numpy as np
 import pytest
@@ -74,6 +75,36 @@ def test_dd_coarse_forward_equals_its_parts(ops, n, nc, white, blender, with_noi
     assert len(rec) == len(rec2) == 3
     for a, b in zip(rec, rec2):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("perturb,pad", [(False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("n,nc,nf", [(4096, 64, 128), (37, 64, 128), (50, 16, 16), (9, 33, 40), (130, 128, 64), (5, 1, 8)])
+def test_dd_coarse_forward_with_the_sampler_folded_in(ops, n, nc, nf, perturb, pad):
+    """the coarse launch that also draws the fine fenceposts: every output of the launch without the sampler, and samples bit for bit
+    those of the stand-alone sampler kernel on that launch's weights / mus / smoothed head values (rows with all-zero weights, the
+    nc = 1 special case of models/samplers.py:185-190 and row lengths off the sort network's power-of-two sizes included)"""
+    rays, t, raw = _coarse_inputs(n, nc, 11 + n, zero_rows=True)
+    noise = torch.randn(n, nc, device="cuda")
+    smooth, dist_reg, near, far = 1.7, 0.0156, 2.0, 6.0
+    ns = nf + 1
+    if perturb:
+        u_base = (torch.arange(ns) * (1 / (ns - 1))).float().cuda()
+        rnd = torch.rand(n, ns, device="cuda")
+    else:
+        u_base, rnd = torch.linspace(0.0, 0.9999, ns).cuda(), None
+    c, head, ticket = ops.dd_coarse_forward(raw, t, rays, noise, smooth, dist_reg, False, True)
+    rec = ops.dd_records_finish(ticket)
+    want = ops.sample_pdf_mu_sigma(t, c["weights"], head["mus"], head["ssig"], head["spart"], head["sleft"], u_base, rnd, near, far, pad)
+    c2, head2, ticket2, got = ops.dd_coarse_forward(raw, t, rays, noise, smooth, dist_reg, False, True, sample=(u_base, rnd, near, far, pad))
+    rec2 = ops.dd_records_finish(ticket2)
+    eq = lambda a, b: torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+    assert got.shape == want.shape == (n, ns) and eq(got, want)
+    for k in head:
+        assert eq(head[k], head2[k]), k
+    for k in ("rgb_map", "disp", "acc", "weights", "depth", "cdisp"):
+        assert eq(c[k], c2[k]), k
+    for a, b in zip(rec, rec2):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dp_blender", [True, False])

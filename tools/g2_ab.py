@@ -17,6 +17,7 @@ def main():
     M = 524288
     runs = []
     for so in sys.argv[1:]:
+        torch.manual_seed(0)                      # (every library gets the same feature rows)
         L, launch, keep = g2_clock.setup(so, M)
         runs.append((os.path.basename(so), launch, keep))
     outs = []
