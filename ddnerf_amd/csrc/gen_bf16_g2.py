@@ -53,13 +53,16 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 #   touch=<file>      code-page touch: every block starts with an s_load_dword from the code address listed for it in <file> (one signed
 #                     byte offset from the s_getpc at the body's top per block; `nop` = a filler of the same size) -- see tools/g2_touch.py
 #   nodma=1 / nox=1   TIMING ONLY, results wrong: no LDS-DMA pieces / no feature fetches are issued
-#   nopf=1            the L2 prefetch touches of feature rows are not issued (results unchanged: they load into a register nothing reads)
+#   pf=1              the L2 prefetch touches of feature rows of rounds 3's body are issued again (a load of one word of each row of a group into
+#                     a register nothing reads, one or two passes ahead of the group's feature fetch; results unchanged).  Round 4
+#                     measured them as a net loss (profiles/r04_g2_experiments.md): the body without them runs 0.4 - 1.3 % faster in
+#                     interleaved A/B, and a code-page crossing costs ~200 cycles instead of ~400 without them
 #   pfpolicy=a_b      cache-policy bits of the L2 prefetch touches (default: none)
 #   xsame=1           TIMING ONLY, results wrong: every tile fetches tile 0's feature rows (the fetches stay, their footprint goes)
 #   touchglc=1        the code-page touches bypass the scalar cache (glc)
 #   xpolicy=a_b       cache-policy bits of the feature fetches instead of `nt` (underscores for spaces; `none` = default policy)
 EXP_DEFAULT = dict(stamp_periods="0", stamp_ksteps="", sgpr_stamps="", dummy_valu="0,0", skip_fill="", skip_every="1", head_pad="0", align="0",
-                   dma_span="1/1", touch="", nodma="0", nox="0", nopf="0", xpolicy="nt", pfpolicy="none", xsame="0", touchglc="0")
+                   dma_span="1/1", touch="", nodma="0", nox="0", pf="0", xpolicy="nt", pfpolicy="none", xsame="0", touchglc="0")
 EXP = dict(EXP_DEFAULT)
 
 
@@ -84,7 +87,7 @@ def set_experiment(opts):
     if SGPR_STAMPS:
         assert 0 <= SGPR_STAMPS[0] < SGPR_STAMPS[1] and SGPR_STAMPS[1] - SGPR_STAMPS[0] <= NSTAMP_SGPR - 1, "sgpr_stamps: at most %d blocks" % (NSTAMP_SGPR - 1)
     TOUCH = [x for x in open(EXP["touch"]).read().split()] if EXP["touch"] else None
-    NODMA, NOX, NOPF = EXP["nodma"] == "1", EXP["nox"] == "1", EXP["nopf"] == "1"
+    NODMA, NOX, NOPF = EXP["nodma"] == "1", EXP["nox"] == "1", EXP["pf"] != "1"
     XPOLICY = "" if EXP["xpolicy"] == "none" else " " + EXP["xpolicy"].replace("_", " ")
     PFPOLICY = "" if EXP["pfpolicy"] == "none" else " " + EXP["pfpolicy"].replace("_", " ")
     XSAME, TOUCHGLC = EXP["xsame"] == "1", EXP["touchglc"] == "1"

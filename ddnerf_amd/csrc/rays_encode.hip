@@ -289,26 +289,48 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
         }
     }
     __syncthreads();
-    // phase 2: IPE, 3 thread-rounds of 256: thread -> (pair p in 0..47, sample ls); the sample is the FAST index, so a wave covers
-    // four pairs = at most two octaves, and the octaves whose arguments stay below 100 pi (the low ones) skip safe_sin's remainder
-    // as a wave
-    for (int e = tid; e < ENC_SPB * 48; e += 256) {
-        int p = e / ENC_SPB, ls = e % ENC_SPB;
-        int l = p / 3, a = p % 3;
-        float s = (float)(1 << l);
+    // phase 2: IPE.  Thread -> (sample ls = tid % 32, q = tid / 32): the six pairs 6q .. 6q + 5 = octaves 2q and 2q + 1 of the three axes.
+    // The sample's Gaussian comes out of LDS ONCE (six reads, one wait) and the six pairs are straight-line code: no per-pair index
+    // arithmetic, no LDS round trip per pair (the loop this replaces spent ~45 instructions and two exposed LDS reads per pair; the
+    // arithmetic per value is unchanged: same outputs).  A wave = two values of q = four consecutive octaves: the low ones, whose
+    // arguments stay below 100 pi, skip safe_sin's remainder as a wave.
+    static_assert(ENC_SPB == 32, "phase 2 maps 256 threads onto 32 samples x 8 octave pairs");
+    {
+        const int ls = tid & (ENC_SPB - 1), q = tid / ENC_SPB;
         const bool live = m0 + ls < M;
-        float y = live ? g_mean[ls][a] * s : 0.0f;                            // :130
-        float yv = live ? g_cov[ls][a] * (s * s) : 0.0f;                      // :131
-        float damp = BF16 ? fast_exp_neg(-0.5f * yv) : enc_exp_neg(-0.5f * yv);   // :149  (yv >= 0)
-        float ys = y, yc = y + 1.57079637f;                                   // :143  y + 0.5*fp32(pi)
+        float mean[3], cov[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mean[a] = live ? g_mean[ls][a] : 0.0f;
+            cov[a] = live ? g_cov[ls][a] : 0.0f;
+        }
         const float T = 314.159271f;                                          // 100 * fp32(pi), general_utils/math_utils.py:155
-        if (__builtin_amdgcn_ballot_w64(!(fabsf(ys) < T) || !(fabsf(yc) < T)) != 0) {
-            ys = (fabsf(ys) < T) ? ys : remainder_pos(ys, T);
-            yc = (fabsf(yc) < T) ? yc : remainder_pos(yc, T);
+        float ys[6], yc[6], damp[6];
+        bool big = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float s = (float)(1 << (2 * q + k / 3));
+            const int a = k % 3;
+            const float y = mean[a] * s;                                      // :130
+            const float yv = cov[a] * (s * s);                                // :131
+            damp[k] = BF16 ? fast_exp_neg(-0.5f * yv) : enc_exp_neg(-0.5f * yv);   // :149  (yv >= 0)
+            ys[k] = y;
+            yc[k] = y + 1.57079637f;                                          // :143  y + 0.5*fp32(pi)
+            big |= !(fabsf(ys[k]) < T) || !(fabsf(yc[k]) < T);
+        }
+        if (__builtin_amdgcn_ballot_w64(big) != 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                ys[k] = (fabsf(ys[k]) < T) ? ys[k] : remainder_pos(ys[k], T);
+                yc[k] = (fabsf(yc[k]) < T) ? yc[k] : remainder_pos(yc[k], T);
+            }
         }
         if (live) {
-            row[ls][p] = damp * (BF16 ? fast_sin(ys) : enc_sin(ys));
-            row[ls][48 + p] = damp * (BF16 ? fast_sin(yc) : enc_sin(yc));
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                row[ls][6 * q + k] = damp[k] * (BF16 ? fast_sin(ys[k]) : enc_sin(ys[k]));
+                row[ls][48 + 6 * q + k] = damp[k] * (BF16 ? fast_sin(yc[k]) : enc_sin(yc[k]));
+            }
         }
     }
     __syncthreads();
