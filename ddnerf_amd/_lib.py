@@ -79,8 +79,11 @@ _SIGS = {
     "ddnerf_dd_coarse_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ddnerf_dd_coarse_forward": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [c_fp] * 20),
     "ddnerf_dd_coarse_sample_forward": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [c_fp] * 19
-                                        + [c_fp, c_fp, C.c_float, C.c_float, c_fp, C.c_int, C.c_int, c_fp]),
+                                        + [c_fp, c_fp, C.c_float, C.c_float, c_fp, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, c_fp]),
+    "ddnerf_debug_philox_normal": (C.c_int, [c_fp, C.c_long, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, c_fp]),
     "ddnerf_composite_forward_keep": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int] + [c_fp] * 8),
+    "ddnerf_composite_forward_keep_rng": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int] + [c_fp] * 7
+                                          + [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, c_fp]),
     "ddnerf_dp_loss_forward_kept": (C.c_int, [c_fp] * 8 + [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_mlp_f32_wgrad_workspace_floats": (C.c_size_t, [C.c_long]),
     "ddnerf_mlp_f32_wgrad": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,

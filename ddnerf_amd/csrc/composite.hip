@@ -30,6 +30,40 @@ struct HeadOut {
 // models/samplers.py:124-215, called at models/models.py:227-237 with exactly what this kernel has just computed: the returned weights, the
 // head's mus and its SMOOTHED sigmas / part-inside / left tails) -- dd_sample_row of sampler_device.h, the stand-alone sampler kernel's
 // code, fed from LDS instead of from the arrays this kernel also writes to memory.  One launch and five [n, nc] reads less per chunk.
+// noise == NULL and ng.on: the density noise randn * std of volume_rendering_utils.py:29-37 is drawn INSIDE the kernel instead of being
+// read from a tensor a generator launch wrote: element (ray, j) of this pass is Philox4x32-10 under the key (seed ^ a constant),
+// counter (ng.base + ray * S + j, offset), two of its words through Box-Muller -- a pure function of (seed, offset, element), so a
+// replay of the same torch generator state reproduces it.  The host takes (seed, offset) from torch's CUDA generator and advances
+// its offset like any torch random kernel would (ddnerf_amd/models.py).  ddnerf_debug_philox_normal writes the same values to memory
+// (the tests composite once with the in-kernel noise and once with that tensor: bit-identical outputs).
+struct NoiseGen {
+    unsigned long long seed, offset, base;
+    float std;
+    int on;
+};
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+}
+__device__ __forceinline__ float philox_normal(const NoiseGen &ng, unsigned long long elem) {
+    const unsigned long long key = ng.seed ^ 0x9E3779B97F4A7C15ull, e = ng.base + elem;
+    unsigned c[4] = {(unsigned)e, (unsigned)(e >> 32), (unsigned)ng.offset, (unsigned)(ng.offset >> 32)};
+    unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const float u1 = ((float)c[0] + 0.5f) * 2.3283064e-10f;   // (0, 1]: 2^-32 (x + 1/2), rounded -- never 0
+    const float u2 = ((float)c[1] + 0.5f) * 2.3283064e-10f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318548f * u2) * ng.std;
+}
+
 struct SampleArgs {
     const float *u_base, *rnd;
     float *samples;
@@ -43,7 +77,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float *__restrict__ noise, const float *__restrict__ mus, int n, int S, int flags,
     float *__restrict__ rgb_map, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
     float *__restrict__ depth, float *__restrict__ cdisp, float *__restrict__ rgb_out, int *__restrict__ keep_out, HeadOut ho,
-    SampleArgs sa) {
+    SampleArgs sa, NoiseGen ng) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ray = blockIdx.x * COMP_WAVES + wave;
@@ -69,7 +103,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             const size_t m = (size_t)ray * S + j;
             const float *r = raw + m * ldr;
             float delta = (t[j + 1] - t[j]) * dn;                       // :21-23
-            float dens = r[3] + (noise ? noise[m] : 0.0f);              // :40
+            float dens = r[3] + (noise ? noise[m] : (ng.on ? philox_normal(ng, m) : 0.0f));   // :40
             float sig = ddn_softplus(dens - 1.0f);                      // :41
             float a = 1.0f - expf(-sig * delta);                        // :42
             alpha[j] = a;
@@ -215,23 +249,46 @@ DDN_EXPORT int ddnerf_composite_forward(const float *raw, int ldr, const float *
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);  // S <= 512
     hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds,
                        (hipStream_t)stream, raw, ldr, t_vals, rays, noise, mus, n, S, flags, rgb_map, disp, acc,
-                       weights, depth, cdisp, rgb, (int *)nullptr, HeadOut{}, SampleArgs{});
+                       weights, depth, cdisp, rgb, (int *)nullptr, HeadOut{}, SampleArgs{}, NoiseGen{});
     return ddn_launch_status();
 }
 
 // The fine pass of DDNerfModel (render path): compositing + the dp loss's row filter in one launch.  keep [n] int32 is the
 // first array of a ddnerf_dp_loss_workspace_bytes(n) workspace, handed to ddnerf_dp_loss_forward_kept.
-DDN_EXPORT int ddnerf_composite_forward_keep(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
-                                             const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc,
-                                             float *weights, float *depth, float *cdisp, void *dp_workspace, ddnerf_stream_t stream) {
+DDN_EXPORT int ddnerf_composite_forward_keep_rng(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
+                                                 const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc,
+                                                 float *weights, float *depth, float *cdisp, void *dp_workspace, unsigned long long noise_seed,
+                                                 unsigned long long noise_offset, unsigned long long noise_base, float noise_std,
+                                                 ddnerf_stream_t stream) {
     DDN_REQUIRE(raw && t_vals && rays && rgb_map && disp && acc && weights && depth && dp_workspace, DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ldr >= 4, DDNERF_E_RANGE);
     size_t lds = (size_t)COMP_WAVES * 8 * S * sizeof(float);
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
+    const NoiseGen ng{noise_seed, noise_offset, noise_base, noise_std, (!noise && noise_std > 0.0f) ? 1 : 0};
     hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3((n + COMP_WAVES - 1) / COMP_WAVES), dim3(256), lds, (hipStream_t)stream, raw, ldr,
                        t_vals, rays, noise, mus, n, S, flags, rgb_map, disp, acc, weights, depth, cdisp, (float *)nullptr,
-                       (int *)dp_workspace, HeadOut{}, SampleArgs{});
+                       (int *)dp_workspace, HeadOut{}, SampleArgs{}, ng);
+    return ddn_launch_status();
+}
+DDN_EXPORT int ddnerf_composite_forward_keep(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
+                                             const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc,
+                                             float *weights, float *depth, float *cdisp, void *dp_workspace, ddnerf_stream_t stream) {
+    return ddnerf_composite_forward_keep_rng(raw, ldr, t_vals, rays, noise, mus, n, S, flags, rgb_map, disp, acc, weights, depth, cdisp, dp_workspace,
+                                             0ull, 0ull, 0ull, 0.0f, stream);
+}
+
+// the values philox_normal() gives elements [0, count) under (seed, offset, base, std): what the compositing kernels add to the density
+// when they draw their noise themselves (test hook; also a way to materialise that noise)
+__global__ void philox_normal_kernel(float *__restrict__ out, size_t count, NoiseGen ng) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = philox_normal(ng, i);
+}
+DDN_EXPORT int ddnerf_debug_philox_normal(float *out, long count, unsigned long long seed, unsigned long long offset, unsigned long long base,
+                                          float std, ddnerf_stream_t stream) {
+    DDN_REQUIRE(out && count > 0, DDNERF_E_ARG);
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (size_t)count,
+                       NoiseGen{seed, offset, base, std, 1});
     return ddn_launch_status();
 }
 
@@ -582,6 +639,7 @@ DDN_EXPORT size_t ddnerf_dd_coarse_workspace_bytes(int n, int nc) {
     return ddnerf_dd_records_workspace_bytes(n, nc) + 16 + 2 * sizeof(float) * (size_t)((n + COMP_WAVES - 1) / COMP_WAVES);
 }
 
+// (noise == NULL and noise_std > 0: the density noise is drawn in the kernel, see NoiseGen)
 // ... and with samples != NULL also the fine pass's fenceposts [n, ns] (ddnerf_sample_pdf_mu_sigma's arguments u_base [ns], rnd [n, ns] or
 // NULL, near_, far_, pdf_padding; bit for bit that entry point's output on this launch's weights / mus / smoothed head values).
 DDN_EXPORT int ddnerf_dd_coarse_sample_forward(const float *raw6, const float *t_vals, const float *rays, const float *noise, int n, int nc,
@@ -590,7 +648,8 @@ DDN_EXPORT int ddnerf_dd_coarse_sample_forward(const float *raw6, const float *t
                                                float *disp, float *acc, float *weights, float *depth, float *cdisp, float *rec_mus,
                                                float *rec_sigmas, float *rec_ssig, int *rec_total, void *workspace, const float *u_base,
                                                const float *rnd, float near_, float far_, float *samples, int ns, int pdf_padding,
-                                               ddnerf_stream_t stream) {
+                                               unsigned long long noise_seed, unsigned long long noise_offset, unsigned long long noise_base,
+                                               float noise_std, ddnerf_stream_t stream) {
     DDN_REQUIRE(raw6 && t_vals && rays && mus && sigmas && left && part && ssig && sleft && spart && scal, DDNERF_E_ARG);
     DDN_REQUIRE(rgb_map && disp && acc && weights && depth && cdisp && rec_mus && rec_sigmas && rec_ssig && rec_total && workspace, DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
@@ -611,8 +670,9 @@ DDN_EXPORT int ddnerf_dd_coarse_sample_forward(const float *raw6, const float *t
     const int nblocks = (n + COMP_WAVES - 1) / COMP_WAVES;
     float *partials = (float *)(((size_t)(rflags + (size_t)n * nc) + 15) & ~(size_t)15);
     HeadOut ho = {mus, sigmas, left, part, ssig, sleft, spart, partials, rflags, counts, smooth};
+    const NoiseGen ng{noise_seed, noise_offset, noise_base, noise_std, (!noise && noise_std > 0.0f) ? 1 : 0};
     hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(nblocks), dim3(256), lds, st, raw6, 6, t_vals, rays, noise, (const float *)nullptr, n,
-                       nc, flags, rgb_map, disp, acc, weights, depth, cdisp, (float *)nullptr, (int *)nullptr, ho, sa);
+                       nc, flags, rgb_map, disp, acc, weights, depth, cdisp, (float *)nullptr, (int *)nullptr, ho, sa, ng);
     hipLaunchKernelGGL(dd_records_write_kernel, dim3((unsigned)((n + 3) / 4 + 1)), dim3(256), 0, st, rflags, counts, mus, sigmas, ssig, n, nc,
                        rec_mus, rec_sigmas, rec_ssig, rec_total, partials, nblocks, dist_reg, scal);
     return ddn_launch_status();
@@ -625,5 +685,5 @@ DDN_EXPORT int ddnerf_dd_coarse_forward(const float *raw6, const float *t_vals, 
                                         float *rec_sigmas, float *rec_ssig, int *rec_total, void *workspace, ddnerf_stream_t stream) {
     return ddnerf_dd_coarse_sample_forward(raw6, t_vals, rays, noise, n, nc, flags, smooth, dist_reg, mus, sigmas, left, part, ssig, sleft, spart, scal,
                                            rgb_map, disp, acc, weights, depth, cdisp, rec_mus, rec_sigmas, rec_ssig, rec_total, workspace,
-                                           (const float *)nullptr, (const float *)nullptr, 0.0f, 0.0f, (float *)nullptr, 0, 0, stream);
+                                           (const float *)nullptr, (const float *)nullptr, 0.0f, 0.0f, (float *)nullptr, 0, 0, 0ull, 0ull, 0ull, 0.0f, stream);
 }

@@ -39,11 +39,21 @@ class TorchRng:
         both = torch.empty(n * (s0 + s1), dtype=torch.float32, device=device).normal_(0.0, float(std))
         return both[:n * s0].view(n, s0), both[n * s0:].view(n, s1)
 
+    def kernel_noise(self, count, device, std):
+        """`count` normals * std that the compositing kernels draw THEMSELVES (no generator launch, no noise tensor): the Philox (seed,
+        offset) of torch's CUDA generator of `device`, whose offset is advanced by what a torch random kernel of that many elements
+        would consume -- so torch.manual_seed reproduces the render, and later torch draws do not reuse the stream."""
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        off = gen.get_offset()
+        gen.set_offset(off + (count + 3) // 4 * 4)
+        return ops.KernelNoise(gen.initial_seed(), off, 0, std)
+
 
 # render-path launch folding (see DDNerfModel.predict); DDNERF_FUSE_RENDER=0 keeps the one-kernel-per-reference-function path
 import os as _os
 
 FUSE_RENDER = _os.environ.get("DDNERF_FUSE_RENDER", "1") != "0"
+KERNEL_NOISE = _os.environ.get("DDNERF_KERNEL_NOISE", "1") != "0"   # (0: the compositing noise comes from a torch generator launch again)
 
 _const_cache = {}
 
@@ -279,9 +289,14 @@ class DDNerfModel(GeneralMipNerfModel):
         # one generator launch for the compositing noise of both levels where the random source offers it (TorchRng does; a replaying
         # source in the parity tests does not and is asked level by level, in the reference's draw order)
         pair = getattr(self.rng, "randn_scaled_pair", None)
+        kernel_noise = getattr(self.rng, "kernel_noise", None)
         noise_pair = None
         t_vals_1 = None
-        if FUSE_RENDER and pair is not None and mc.radiance_field_noise_std > 0.0:
+        if FUSE_RENDER and mc.radiance_field_noise_std > 0.0 and not torch.is_grad_enabled() and kernel_noise is not None and KERNEL_NOISE:
+            # render path with the default random source: the two compositing launches draw their noise themselves
+            kn = kernel_noise(n * (mc.num_coarse + mc.num_fine), dev, mc.radiance_field_noise_std)
+            noise_pair = (kn.at(0), kn.at(n * mc.num_coarse))
+        elif FUSE_RENDER and pair is not None and mc.radiance_field_noise_std > 0.0:
             noise_pair = pair(n, mc.num_coarse, mc.num_fine, dev, mc.radiance_field_noise_std)
         for i in range(2):
             if i == 1:

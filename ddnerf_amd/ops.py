@@ -318,12 +318,39 @@ def pack_rays_first_cycle(ray_origins, ray_directions, ray_rad, near, far, t_lin
     return rays, t_vals
 
 
+class KernelNoise:
+    """density noise the compositing kernels draw themselves (volume_rendering_utils.py:29-37's randn * std without a generator launch or a
+    noise tensor): (seed, offset) of the Philox stream, `base` = the first element index of this pass, `std`"""
+
+    def __init__(self, seed, offset, base, std):
+        self.seed, self.offset, self.base, self.std = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(base), float(std)
+
+    def at(self, base):
+        return KernelNoise(self.seed, self.offset, base, self.std)
+
+    def materialise(self, count, device):
+        """the values themselves ([count] fp32): what the kernels add to the densities of elements base .. base + count"""
+        out = torch.empty(count, dtype=torch.float32, device=device)
+        _lib.check(_lib.lib().ddnerf_debug_philox_normal(_ptr(out), count, self.seed, self.offset, self.base, self.std, _stream()),
+                   "ddnerf_debug_philox_normal")
+        return out
+
+
+def _noise_args(noise):
+    """(noise tensor or None, seed, offset, base, std) for the *_rng entry points"""
+    if isinstance(noise, KernelNoise):
+        return None, noise.seed, noise.offset, noise.base, noise.std
+    return _f32c(noise, "noise"), 0, 0, 0, 0.0
+
+
 def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, blender, sample=None):
     """The coarse pass of DDNerfModel behind the MLP, render path (models/models.py:242-295), in two launches: DD head + compositing
-    + level-0 records.  -> (composite dict, head dict, records ticket for dd_records_finish).  sample = (u_base [ns], rnd [n,ns] | None,
+    + level-0 records.  -> (composite dict, head dict, records ticket for dd_records_finish).  noise: a tensor, None, or a KernelNoise
+    (the kernel draws the density noise itself).  sample = (u_base [ns], rnd [n,ns] | None,
     near, far, pdf_padding): the first launch also draws the fine pass's fenceposts (sample_pdf_mu_sigma on this pass's weights, mus and
     smoothed head values, bit for bit) -> a fourth result, samples [n, ns]."""
-    raw6, t_vals, rays, noise = _f32c(raw6, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays"), _f32c(noise, "noise")
+    raw6, t_vals, rays = _f32c(raw6, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays")
+    noise, nseed, noff, nbase, nstd = _noise_args(noise)
     n, nc, ldr = raw6.shape
     assert ldr == 6
     dev = raw6.device
@@ -348,7 +375,8 @@ def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, b
         _ptr(raw6), _ptr(t_vals), _ptr(rays), _ptr(noise), n, nc, flags, float(smooth), float(dist_reg),
         *[_ptr(head[k]) for k in ("mus", "sigmas", "left", "part", "ssig", "sleft", "spart", "scal")],
         *[_ptr(c[k]) for k in ("rgb_map", "disp", "acc", "weights", "depth", "cdisp")], *[_ptr(o) for o in outs], _ptr(total), _ptr(ws),
-        _ptr(u_base), _ptr(rnd), float(near_), float(far_), _ptr(samples), int(ns), int(bool(pad)), _stream()), "ddnerf_dd_coarse_sample_forward")
+        _ptr(u_base), _ptr(rnd), float(near_), float(far_), _ptr(samples), int(ns), int(bool(pad)), nseed, noff, nbase, nstd, _stream()),
+        "ddnerf_dd_coarse_sample_forward")
     if sample is None:
         return c, head, _records_ticket(outs, total)
     return c, head, _records_ticket(outs, total), samples
@@ -357,16 +385,18 @@ def dd_coarse_forward(raw6, t_vals, rays, noise, smooth, dist_reg, white_bkgd, b
 def composite_forward_keep(raw, t_vals, rays, noise, mus, white_bkgd, blender, dp_filter):
     """compositing of the fine pass + the dp loss's row filter in one launch -> (composite dict, dp-loss workspace holding keep[n])"""
     raw, t_vals, rays = _f32c(raw, "raw"), _f32c(t_vals, "t_vals"), _f32c(rays, "rays")
-    noise, mus = _f32c(noise, "noise"), _f32c(mus, "mus")
+    noise, nseed, noff, nbase, nstd = _noise_args(noise)
+    mus = _f32c(mus, "mus")
     n, S, ldr = raw.shape
     dev = raw.device
     e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     o = dict(rgb_map=e(n, 3), disp=e(n), acc=e(n), weights=e(n, S), depth=e(n), cdisp=e(n) if mus is not None else None, rgb=None)
     ws = torch.empty(_lib.lib().ddnerf_dp_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
     flags = (1 if white_bkgd else 0) | (2 if blender else 0) | (4 if dp_filter else 0)
-    _lib.check(_lib.lib().ddnerf_composite_forward_keep(_ptr(raw), ldr, _ptr(t_vals), _ptr(rays), _ptr(noise), _ptr(mus), n, S, flags,
-                                                        _ptr(o["rgb_map"]), _ptr(o["disp"]), _ptr(o["acc"]), _ptr(o["weights"]),
-                                                        _ptr(o["depth"]), _ptr(o["cdisp"]), _ptr(ws), _stream()), "ddnerf_composite_forward_keep")
+    _lib.check(_lib.lib().ddnerf_composite_forward_keep_rng(_ptr(raw), ldr, _ptr(t_vals), _ptr(rays), _ptr(noise), _ptr(mus), n, S, flags,
+                                                            _ptr(o["rgb_map"]), _ptr(o["disp"]), _ptr(o["acc"]), _ptr(o["weights"]),
+                                                            _ptr(o["depth"]), _ptr(o["cdisp"]), _ptr(ws), nseed, noff, nbase, nstd, _stream()),
+               "ddnerf_composite_forward_keep_rng")
     return o, ws
 
 

@@ -262,19 +262,33 @@ int ddnerf_dd_coarse_forward(const float *raw6, const float *t_vals, const float
 /* ... and with the fine pass's fenceposts drawn in the SAME first launch (samples != NULL): sample_pdf_with_mu_sigma (models/samplers.py:124-215,
  * called at models/models.py:227-237 with this pass's returned weights, the head's mus and its smoothed sigmas / part-inside / left tails),
  * i.e. ddnerf_sample_pdf_mu_sigma's u_base [ns], rnd [n,ns] or NULL, near_, far_, pdf_padding -> samples [n,ns], bit for bit that entry
- * point's output.  samples == NULL: ddnerf_dd_coarse_forward. */
+ * point's output.  samples == NULL: ddnerf_dd_coarse_forward.
+ * noise == NULL and noise_std > 0: the kernel draws the density noise randn * noise_std (volume_rendering_utils.py:29-37) itself -- element
+ * (ray, j) = Philox4x32-10 under (noise_seed, noise_offset) at counter noise_base + ray * nc + j, through Box-Muller: a pure function of its
+ * arguments (ddnerf_debug_philox_normal materialises it), so no generator launch and no noise tensor precede the launch. */
 int ddnerf_dd_coarse_sample_forward(const float *raw6, const float *t_vals, const float *rays, const float *noise, int n, int nc, int flags,
                                     float smooth, float dist_reg, float *mus, float *sigmas, float *left, float *part, float *ssig,
                                     float *sleft, float *spart, float *scal, float *rgb_map, float *disp, float *acc, float *weights,
                                     float *depth, float *cdisp, float *rec_mus, float *rec_sigmas, float *rec_ssig, int *rec_total,
                                     void *workspace, const float *u_base, const float *rnd, float near_, float far_, float *samples, int ns,
-                                    int pdf_padding, ddnerf_stream_t stream);
+                                    int pdf_padding, unsigned long long noise_seed, unsigned long long noise_offset,
+                                    unsigned long long noise_base, float noise_std, ddnerf_stream_t stream);
 /* The fine pass: compositing + the dp loss's row filter (models/dd_utils.py:16: torch.sum(w1) > 1e-10 IS the compositing's
  * weight sum) in one launch; dp_workspace = a ddnerf_dp_loss_workspace_bytes(n) buffer, then handed to
  * ddnerf_dp_loss_forward_kept, which is ddnerf_dp_loss_forward without its first launch. */
 int ddnerf_composite_forward_keep(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
                                   const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc, float *weights,
                                   float *depth, float *cdisp, void *dp_workspace, ddnerf_stream_t stream);
+/* ... with the density noise drawn in the kernel when noise == NULL and noise_std > 0 (see ddnerf_dd_coarse_sample_forward) */
+int ddnerf_composite_forward_keep_rng(const float *raw, int ldr, const float *t_vals, const float *rays, const float *noise,
+                                      const float *mus, int n, int S, int flags, float *rgb_map, float *disp, float *acc,
+                                      float *weights, float *depth, float *cdisp, void *dp_workspace, unsigned long long noise_seed,
+                                      unsigned long long noise_offset, unsigned long long noise_base, float noise_std,
+                                      ddnerf_stream_t stream);
+/* out[i] = the noise value of element noise_base + i under (seed, offset, std), i in [0, count): what the two entry points above add to
+ * the density of that element. */
+int ddnerf_debug_philox_normal(float *out, long count, unsigned long long seed, unsigned long long offset, unsigned long long base,
+                               float std, ddnerf_stream_t stream);
 int ddnerf_dp_loss_forward_kept(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,
                                 const float *sig0, const float *left0, const float *part0, int n, int nc, int nf, float *loss,
                                 const float *reg_scal, float *loss_total, void *workspace, ddnerf_stream_t stream);

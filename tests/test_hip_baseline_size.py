@@ -151,29 +151,33 @@ def _training_curve(name, mlp_dtype, monkeypatch):
 @pytest.mark.parametrize("name", ["train300_dd_blender", "train300_mip_blender"])
 def test_training_curve_tracks_the_reference(name, mlp_dtype, monkeypatch):
     """300 iterations (fresh 256-ray batch per iteration, analytic targets, perturb / noise off, 50-step lr warm-up): the HIP
-    path's loss and PSNR, every 10 iterations, against the reference loop's.  Two fp32 implementations of one chaotic
-    optimisation drift apart slowly: the curves are held to 0.35 dB everywhere and 0.2 dB over the last 50 iterations' mean."""
+    path's loss and PSNR, every 10 iterations, against the reference loop's.  Measured in round 4 (tools/train_curve_stats.py): every tier
+    within 0.002 dB of the reference at every recorded iteration, losses within 0.05 % -- held to 0.05 dB / 0.02 dB (mean of the last
+    50 iterations) / 0.5 %."""
     got_loss, got_mse, g = _training_curve(name, mlp_dtype, monkeypatch)
     ref_loss, ref_mse = g["loss"], g["mse"]
     assert ref_mse[-1, 1] < 0.35 * ref_mse[0, 1]                       # the reference run really learns (about 5 dB in 300 steps)
     assert abs(got_loss[0] - ref_loss[0]) <= 2e-5 * max(1.0, abs(ref_loss[0]))   # iteration 0: plain forward parity
     d_psnr = np.abs(_psnr(got_mse) - _psnr(ref_mse))
-    assert d_psnr.max() <= 0.35, (d_psnr.max(), int(d_psnr.argmax()))
-    assert abs(_psnr(got_mse[-6:, 1]).mean() - _psnr(ref_mse[-6:, 1]).mean()) <= 0.2
-    assert np.all(np.abs(got_loss - ref_loss) <= 0.08 * np.abs(ref_loss) + 1e-5)
+    assert d_psnr.max() <= 0.05, (d_psnr.max(), int(d_psnr.argmax()))
+    assert abs(_psnr(got_mse[-6:, 1]).mean() - _psnr(ref_mse[-6:, 1]).mean()) <= 0.02
+    assert np.all(np.abs(got_loss - ref_loss) <= 0.005 * np.abs(ref_loss) + 1e-5)
 
 
 @pytest.mark.parametrize("mlp_dtype", ["fp32", "x3", "x3-exact"])
 def test_training_curve_1500_iterations_of_the_real_schedule(mlp_dtype, monkeypatch):
     """The FIRST 1500 steps of a real run: the schedule train_model.py hard-wires (:101-107 -- 5e-4 -> 5e-6 over the config's
     train_iters with the 2500-step x0.01 warm-up), DDNerfModel, 256 fresh rays per iteration, loss / PSNR every 25 iterations against
-    the reference loop's (tests/golden/train1500_dd_blender.npz, make_golden.py gen_train1500).  Held like the 300-step curves: 0.35 dB
-    everywhere, 0.2 dB over the mean of the last 150 iterations, loss within 8 %."""
+    the reference loop's (tests/golden/train1500_dd_blender.npz, make_golden.py gen_train1500): PSNR 11.9 -> 29.8 dB.  Two fp32-class
+    implementations of one chaotic optimisation drift apart slowly: measured in round 4 (tools/train_curve_stats.py) -- max |d PSNR| at any
+    recorded iteration 0.47 dB (fp32 tier) / 0.66 (x3) / 0.72 (x3, exact records), all three at iteration 1075; mean over the records
+    0.07 - 0.09 dB; mean of the last 150 iterations within 0.009 dB; losses within 4 - 6 %.  Held to 1.0 dB / 0.15 dB / 0.1 dB / 10 %."""
     got_loss, got_mse, g = _training_curve("train1500_dd_blender", mlp_dtype, monkeypatch)
     ref_loss, ref_mse = g["loss"], g["mse"]
-    assert ref_mse[-1, 1] < 0.5 * ref_mse[0, 1]                        # the reference run learns inside the warm-up too
+    assert ref_mse[-1, 1] < 0.05 * ref_mse[0, 1]                       # the reference run learns: 18 dB in these 1500 steps
     assert abs(got_loss[0] - ref_loss[0]) <= 2e-5 * max(1.0, abs(ref_loss[0]))
     d_psnr = np.abs(_psnr(got_mse) - _psnr(ref_mse))
-    assert d_psnr.max() <= 0.35, (d_psnr.max(), int(d_psnr.argmax()))
-    assert abs(_psnr(got_mse[-6:, 1]).mean() - _psnr(ref_mse[-6:, 1]).mean()) <= 0.2
-    assert np.all(np.abs(got_loss - ref_loss) <= 0.08 * np.abs(ref_loss) + 1e-5)
+    assert d_psnr.max() <= 1.0, (d_psnr.max(), int(d_psnr.argmax()))
+    assert d_psnr.mean() <= 0.15, d_psnr.mean()
+    assert abs(_psnr(got_mse[-6:, 1]).mean() - _psnr(ref_mse[-6:, 1]).mean()) <= 0.1
+    assert np.all(np.abs(got_loss - ref_loss) <= 0.10 * np.abs(ref_loss) + 1e-5)

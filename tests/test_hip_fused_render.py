@@ -165,3 +165,88 @@ def test_run_iter_same_outputs_with_and_without_folding(name):
                     assert torch.allclose(x, y, rtol=3e-6, atol=0), (lvl, k)
                 else:
                     assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)), (lvl, k)
+
+
+def test_kernel_drawn_noise_is_the_materialised_noise(ops):
+    """the density noise the compositing kernels draw themselves (Philox4x32-10 + Box-Muller keyed by torch's generator state): compositing
+    with it is BIT-IDENTICAL to compositing with the tensor ddnerf_debug_philox_normal writes for the same (seed, offset, base, std) --
+    coarse launch (with the sampler folded in) and fine launch"""
+    n, nc, nf = 513, 64, 128
+    rays, t0, raw0 = _coarse_inputs(n, nc, 21)
+    _, t1, raw1 = _coarse_inputs(n, nf, 22)
+    raw1 = raw1[..., :4].contiguous()
+    kn = ops.KernelNoise(seed=1234567, offset=40, base=0, std=0.7)
+    u_base = torch.linspace(0.0, 0.9999, nf + 1).cuda()
+    sample = (u_base, None, 2.0, 6.0, True)
+    a = ops.dd_coarse_forward(raw0, t0, rays, kn.at(0), 1.7, 0.0156, False, True, sample=sample)
+    b = ops.dd_coarse_forward(raw0, t0, rays, kn.at(0).materialise(n * nc, raw0.device).view(n, nc), 1.7, 0.0156, False, True, sample=sample)
+    for k in ("rgb_map", "disp", "acc", "weights", "depth", "cdisp"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    assert torch.equal(a[3], b[3])
+    ops.dd_records_finish(a[2])
+    ops.dd_records_finish(b[2])
+    c, _ = ops.composite_forward_keep(raw1, t1, rays, kn.at(n * nc), None, False, True, True)
+    d, _ = ops.composite_forward_keep(raw1, t1, rays, kn.at(n * nc).materialise(n * nf, raw1.device).view(n, nf), None, False, True, True)
+    for k in ("rgb_map", "disp", "acc", "weights", "depth"):
+        assert torch.equal(c[k], d[k]), k
+    e, _ = ops.composite_forward_keep(raw1, t1, rays, None, None, False, True, True)
+    assert not torch.equal(c["weights"], e["weights"])                      # (the noise really enters)
+
+
+def test_kernel_drawn_noise_is_standard_normal(ops):
+    """2^22 values: moments of N(0, std^2), a Kolmogorov-Smirnov distance of a sample that size, no repeats between streams"""
+    N, std = 1 << 22, 1.0
+    kn = ops.KernelNoise(seed=42, offset=0, base=0, std=std)
+    x = kn.materialise(N, torch.device("cuda")).double()
+    assert torch.isfinite(x).all()
+    assert abs(float(x.mean())) < 5 * std / N ** 0.5 and abs(float(x.std()) - std) < 3e-3
+    z = x / std
+    assert abs(float((z ** 3).mean())) < 0.01 and abs(float((z ** 4).mean()) - 3.0) < 0.03
+    xs = torch.sort(z)[0]
+    cdf = 0.5 * (1 + torch.erf(xs / 2 ** 0.5))
+    emp = (torch.arange(1, N + 1, device="cuda", dtype=torch.float64)) / N
+    assert float((cdf - emp).abs().max()) < 2.5 / N ** 0.5                    # (1.63 / sqrt(N) is the 1 % point)
+    assert float(x.abs().max()) > 4.5                                           # the tails are there (Box-Muller on 32-bit uniforms reaches 6.6)
+    # another offset, another seed, another base: other values; the same arguments: the same values
+    assert torch.equal(x.float(), kn.materialise(N, torch.device("cuda")).double().float())
+    for other in (ops.KernelNoise(42, 4, 0, std), ops.KernelNoise(43, 0, 0, std), kn.at(N)):
+        y = other.materialise(4096, torch.device("cuda")).double()
+        assert float((y == x[:4096]).double().mean()) < 0.01
+        assert abs(float(torch.corrcoef(torch.stack([y, x[:4096]]))[0, 1])) < 0.08
+    assert torch.equal(kn.at(100).materialise(50, torch.device("cuda")), x[100:150].float())   # base = an index into ONE stream
+
+
+def test_render_with_kernel_noise_follows_torch_seeding():
+    """run_iter(mode="validation") with the shipped noise std 1.0: torch.manual_seed reproduces the render, two renders in a row differ
+    (the generator's offset advances), and DDNERF_KERNEL_NOISE=0 (a torch generator launch again) gives a statistically equal image"""
+    from _cases import load_runiter
+    from ddnerf_amd import models as M
+    from test_hip_run_iter import build_model
+
+    c = load_runiter("runiter_dd_blender_64x128_validation")
+    g = c["g"]
+    d = lambda x: torch.from_numpy(x).cuda()
+    model = build_model(c)
+    model.rng = M.TorchRng()
+    for mode in ("train", "validation"):
+        model.cfg.nerf[mode]["radiance_field_noise_std"] = 1.0
+    model.eval()
+    outs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            outs.append(model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode="validation", rgb_target=d(g["tgt"])))
+            again = model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode="validation", rgb_target=d(g["tgt"]))
+        assert not torch.equal(outs[-1][1]["rgb"], again[1]["rgb"])
+    assert torch.equal(outs[0][1]["rgb"], outs[1][1]["rgb"]) and torch.equal(outs[0][0]["weights"], outs[1][0]["weights"])
+    assert not torch.equal(outs[0][1]["rgb"], outs[2][1]["rgb"])
+    M.KERNEL_NOISE = False
+    try:
+        torch.manual_seed(7)
+        with torch.no_grad():
+            ref = model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode="validation", rgb_target=d(g["tgt"]))
+    finally:
+        M.KERNEL_NOISE = True
+    # two independent noise draws of the same render: the images differ by noise, not by a bias
+    diff = (ref[1]["rgb"] - outs[0][1]["rgb"])
+    assert float(diff.abs().max()) > 0 and abs(float(diff.mean())) < 0.25 * float(diff.std()) + 1e-4
