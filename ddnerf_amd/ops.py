@@ -400,16 +400,34 @@ def composite_forward_keep(raw, t_vals, rays, noise, mus, white_bkgd, blender, d
     return o, ws
 
 
+_DP_TICKETS = {}   # (device, stream) -> [int64 counter tensor, workgroups launched on it so far]
+DP_ONE_LAUNCH = os.environ.get("DDNERF_DP_ONE_LAUNCH", "1") != "0"
+
+
 def dp_loss_forward_kept(t1, t0, w1, w0, mus0, sig0, left0, part0, ws, reg_scal):
-    """dp_loss_forward behind composite_forward_keep (the row filter is in `ws` already) -> (loss, total [1])"""
+    """dp_loss_forward behind composite_forward_keep (the row filter is in `ws` already) -> (loss, total [1]).  ONE launch: the workgroup
+    that takes the launch's last ticket adds up the row sums (ddnerf_dp_loss_forward_kept1; the counter lives per device and stream, where
+    launches are ordered); DDNERF_DP_ONE_LAUNCH=0: the rows kernel and the finish kernel (same bits)."""
     t1, t0, w1, w0, mus0, sig0, left0, part0 = (_f32c(t, "dp_loss arg") for t in (t1, t0, w1, w0, mus0, sig0, left0, part0))
     n, nc = w0.shape
     nf = w1.shape[1]
     loss = torch.empty((), dtype=torch.float32, device=w0.device)
     total = torch.empty(1, dtype=torch.float32, device=w0.device)
-    _lib.check(_lib.lib().ddnerf_dp_loss_forward_kept(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0), _ptr(part0),
-                                                      n, nc, nf, _ptr(loss), _ptr(_f32c(reg_scal, "reg_scal")), _ptr(total), _ptr(ws), _stream()),
-               "ddnerf_dp_loss_forward_kept")
+    L = _lib.lib()
+    if not DP_ONE_LAUNCH:
+        _lib.check(L.ddnerf_dp_loss_forward_kept(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0), _ptr(part0),
+                                                 n, nc, nf, _ptr(loss), _ptr(_f32c(reg_scal, "reg_scal")), _ptr(total), _ptr(ws), _stream()),
+                   "ddnerf_dp_loss_forward_kept")
+        return loss, total
+    st = _stream()
+    key = (str(w0.device), st)
+    slot = _DP_TICKETS.get(key)
+    if slot is None:
+        slot = _DP_TICKETS[key] = [torch.zeros(1, dtype=torch.int64, device=w0.device), 0]
+    _lib.check(L.ddnerf_dp_loss_forward_kept1(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0), _ptr(part0),
+                                              n, nc, nf, _ptr(loss), _ptr(_f32c(reg_scal, "reg_scal")), _ptr(total), _ptr(ws), _ptr(slot[0]),
+                                              slot[1], st), "ddnerf_dp_loss_forward_kept1")
+    slot[1] += int(L.ddnerf_dp_loss_ticket_blocks(n))
     return loss, total
 
 

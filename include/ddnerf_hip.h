@@ -292,6 +292,15 @@ int ddnerf_debug_philox_normal(float *out, long count, unsigned long long seed, 
 int ddnerf_dp_loss_forward_kept(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,
                                 const float *sig0, const float *left0, const float *part0, int n, int nc, int nf, float *loss,
                                 const float *reg_scal, float *loss_total, void *workspace, ddnerf_stream_t stream);
+/* ... in ONE launch: the workgroup that takes the launch's last ticket adds up the row sums (bit for bit ddnerf_dp_loss_forward_kept's
+ * loss / loss_total).  ticket: a 64-bit device counter that starts at 0 and is handed to nothing but this entry point; ticket_base: the
+ * number of workgroups launched on it so far = the sum of ddnerf_dp_loss_ticket_blocks(n) over the earlier calls (all ordered before this
+ * one, e.g. enqueued on the same stream). */
+long ddnerf_dp_loss_ticket_blocks(int n);
+int ddnerf_dp_loss_forward_kept1(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0, const float *sig0,
+                                 const float *left0, const float *part0, int n, int nc, int nf, float *loss, const float *reg_scal,
+                                 float *loss_total, void *workspace, unsigned long long *ticket, unsigned long long ticket_base,
+                                 ddnerf_stream_t stream);
 
 /* backward of estimate_dp_loss w.r.t. (w0, mus0, sig0); g_loss[0] = upstream gradient of the scalar loss.
  * workspace as for the forward. */

@@ -120,7 +120,13 @@ def test_fine_compositing_with_row_filter(ops, n, nc, nf, dp_blender):
         args = (t1, t0, c1["weights"], c0["weights"], head["mus"], head["sigmas"], head["left"], head["part"])
         loss_a, total_a = ops.dp_loss_forward(*args, dp_blender, reg_scal=head["scal"])
         c1b, ws = ops.composite_forward_keep(raw1, t1, rays, None, None, False, blender, dp_blender)
-        loss_b, total_b = ops.dp_loss_forward_kept(*args[:2], c1b["weights"], *args[3:], ws, head["scal"])
+        loss_b, total_b = ops.dp_loss_forward_kept(*args[:2], c1b["weights"], *args[3:], ws, head["scal"])    # (one launch: last-ticket finish)
+        ops.DP_ONE_LAUNCH = False
+        try:
+            loss_c, total_c = ops.dp_loss_forward_kept(*args[:2], c1b["weights"], *args[3:], ws, head["scal"])   # rows kernel + finish kernel
+        finally:
+            ops.DP_ONE_LAUNCH = True
+        assert torch.equal(loss_b, loss_c) and torch.equal(total_b, total_c)
         for k in ("rgb_map", "disp", "acc", "weights", "depth"):
             a, b = c1[k], c1b[k]
             assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), k
@@ -250,3 +256,27 @@ def test_render_with_kernel_noise_follows_torch_seeding():
     # two independent noise draws of the same render: the images differ by noise, not by a bias
     diff = (ref[1]["rgb"] - outs[0][1]["rgb"])
     assert float(diff.abs().max()) > 0 and abs(float(diff.mean())) < 0.25 * float(diff.std()) + 1e-4
+
+
+def test_dp_loss_one_launch_many_times(ops):
+    """the last-ticket finish reads row sums other workgroups -- on other XCDs -- stored microseconds earlier: 300 launches back to back on
+    fresh weights, every loss compared bit for bit with the two-launch path (a stale row sum would show as a mismatch)"""
+    n, nc, nf = 4096, 64, 128
+    rays, t0, raw0 = _coarse_inputs(n, nc, 31)
+    head = ops.dd_head(raw0, 1.7, 0.0156)
+    c0 = ops.composite_forward(raw0, t0, rays, None, head["mus"], False, True)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    bad = 0
+    for it in range(300):
+        _, t1, raw1 = _coarse_inputs(n, nf, 100 + it, zero_rows=(it % 3 == 0))
+        raw1 = (raw1[..., :4] + 0.1 * torch.randn(n, nf, 4, device="cuda", generator=g)).contiguous()
+        c1, ws = ops.composite_forward_keep(raw1, t1, rays, None, None, False, True, True)
+        args = (t1, t0, c1["weights"], c0["weights"], head["mus"], head["sigmas"], head["left"], head["part"])
+        a = ops.dp_loss_forward_kept(*args, ws, head["scal"])
+        ops.DP_ONE_LAUNCH = False
+        try:
+            b = ops.dp_loss_forward_kept(*args, ws, head["scal"])
+        finally:
+            ops.DP_ONE_LAUNCH = True
+        bad += int(not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])))
+    assert bad == 0, bad
