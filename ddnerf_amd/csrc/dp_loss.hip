@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void dpl_keep_kernel(const float *__restrict__
 // exclusive scan of keep[0..n) by ONE 1024-thread block (n <= a few 10^4 rows per chunk)
 
 // The finish step inside the rows kernel (render path: one launch less): the workgroup that takes the LAST ticket of the launch adds up the
-// row sums -- by then every other workgroup has stored its rows' sums with agent-scope stores, drained them, and released (one lane:
-// agent-scope release fence, then the ticket add); the last workgroup acquires after its own add returns.  The reduction reproduces
+// row sums -- by then every other workgroup has stored its rows' sums with agent-scope (sc1, write-through) stores, drained them
+// (s_waitcnt vmcnt(0) in every storing wave, then the workgroup's barrier) and added its ticket (one lane, agent-scope atomic); the
+// last workgroup acquires (agent scope) after its own add returns and reads the sums with sc1 loads.  The reduction reproduces
 // dpl_finish_kernel's arithmetic exactly: its 1024 "threads" are 4 per lane here, and the tree pairs the same partners in the same
 // order, so the loss is bit for bit the two-launch path's.  ticket: one 64-bit counter that only ever grows (every workgroup of every
 // launch adds 1); the host passes the value it had before the launch (it knows how many workgroups it has launched on it).
@@ -93,7 +94,7 @@ __device__ __forceinline__ void dpl_finish_in_block(const float *__restrict__ ro
     const int R = cnt[0];  // kept rows
     for (int v = tid; v < 1024; v += 256) {
         double s = 0.0;
-        for (int r = v; r < R; r += 1024) s += (double)rowsum[r];
+        for (int r = v; r < R; r += 1024) s += (double)__hip_atomic_load(&rowsum[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (sc1 loads)
         part[v] = s;
     }
     __syncthreads();
@@ -201,8 +202,12 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
     __shared__ int is_last;
     __syncthreads();
     if (threadIdx.x == 0) {
+#ifdef DPL_RELEASE_FENCE   // (measured: an agent-scope release = an L2 write-back per workgroup, 1024 of them: the kernel 20 -> 39 us)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the wait behind the write-back when the wave's counter is provably empty)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        // the row sums are the ONLY bytes handed over; they left as sc1 (write-through) stores that every storing wave has drained
+        // (s_waitcnt vmcnt(0) in front of the barrier above): nothing of them is left dirty in this XCD's L2 for a release to write back
         const unsigned long long t = __hip_atomic_fetch_add(fin.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = t == fin.base + gridDim.x - 1;
         if (last) {

@@ -246,17 +246,24 @@ def test_render_with_kernel_noise_follows_torch_seeding():
         assert not torch.equal(outs[-1][1]["rgb"], again[1]["rgb"])
     assert torch.equal(outs[0][1]["rgb"], outs[1][1]["rgb"]) and torch.equal(outs[0][0]["weights"], outs[1][0]["weights"])
     assert not torch.equal(outs[0][1]["rgb"], outs[2][1]["rgb"])
-    M.KERNEL_NOISE = False
-    try:
-        torch.manual_seed(7)
-        with torch.no_grad():
-            ref = model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode="validation", rgb_target=d(g["tgt"]))
-    finally:
-        M.KERNEL_NOISE = True
-    # two independent noise draws of the same render: the images differ by noise, not by a bias
-    diff = (ref[1]["rgb"] - outs[0][1]["rgb"])
-    assert float(diff.abs().max()) > 0 and abs(float(diff.mean())) < 0.25 * float(diff.std()) + 1e-4
+    # the same render with a torch generator launch for the noise (DDNERF_KERNEL_NOISE=0): another draw of the same distribution --
+    # the image means over 16 seeds of either source agree within four standard errors
+    def image_means(kernel_noise):
+        M.KERNEL_NOISE = kernel_noise
+        try:
+            vals = []
+            for seed in range(100, 116):
+                torch.manual_seed(seed)
+                with torch.no_grad():
+                    o = model.run_iter(d(g["ro"]), d(g["rd"]), d(g["rad"]), mode="validation", rgb_target=d(g["tgt"]))
+                vals.append(float(o[1]["rgb"].double().mean()))
+            return np.array(vals)
+        finally:
+            M.KERNEL_NOISE = True
 
+    a, b = image_means(True), image_means(False)
+    assert a.std() > 0 and b.std() > 0
+    assert abs(a.mean() - b.mean()) <= 4.0 * np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b)) + 1e-6, (a.mean(), b.mean(), a.std(), b.std())
 
 def test_dp_loss_one_launch_many_times(ops):
     """the last-ticket finish reads row sums other workgroups -- on other XCDs -- stored microseconds earlier: 300 launches back to back on
