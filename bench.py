@@ -420,11 +420,14 @@ def kernel_source_digest(mlp):
 
 def measured_traffic(args):
     """HBM bytes per launch of the fine-MLP kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (profiles/r03_hbm_traffic_<mlp>.json).  Only quoted when that profile was taken on THIS kernel source (digest recorded
+    (profiles/rNN_hbm_traffic_<mlp>.json, the newest round's).  Only quoted when that profile was taken on THIS kernel source (digest recorded
     in the file) and at this launch size; otherwise null."""
-    tf = os.path.join(ROOT, "profiles", "r03_hbm_traffic_%s.json" % args.mlp)
-    if not (os.path.exists(tf) and (args.rays, args.fine) == (4096, 128)):
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic_%s.json" % args.mlp)))
+    if not (found and (args.rays, args.fine) == (4096, 128)):
         return None, None
+    tf = found[-1]
     d = json.load(open(tf))
     if d.get("kernel_source_md5") != kernel_source_digest(args.mlp):
         return None, None

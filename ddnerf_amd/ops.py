@@ -401,13 +401,16 @@ def composite_forward_keep(raw, t_vals, rays, noise, mus, white_bkgd, blender, d
 
 
 _DP_TICKETS = {}   # (device, stream) -> [int64 counter tensor, workgroups launched on it so far]
-DP_ONE_LAUNCH = os.environ.get("DDNERF_DP_ONE_LAUNCH", "1") != "0"
+# (measured, round 4: the one-launch form is SLOWER -- 37.8 us against 20.2 + 4.9 us for the rows kernel and the finish kernel: 1024
+# workgroups take their tickets from ONE counter, ~88 atomics per microsecond, and the finish still runs behind the last of them --
+# so the two launches stay the default; profiles/r04_render_bf16_kernel_stats_dp_one_launch.csv)
+DP_ONE_LAUNCH = os.environ.get("DDNERF_DP_ONE_LAUNCH", "0") == "1"
 
 
 def dp_loss_forward_kept(t1, t0, w1, w0, mus0, sig0, left0, part0, ws, reg_scal):
-    """dp_loss_forward behind composite_forward_keep (the row filter is in `ws` already) -> (loss, total [1]).  ONE launch: the workgroup
-    that takes the launch's last ticket adds up the row sums (ddnerf_dp_loss_forward_kept1; the counter lives per device and stream, where
-    launches are ordered); DDNERF_DP_ONE_LAUNCH=0: the rows kernel and the finish kernel (same bits)."""
+    """dp_loss_forward behind composite_forward_keep (the row filter is in `ws` already) -> (loss, total [1]): the rows kernel and the
+    finish kernel.  DDNERF_DP_ONE_LAUNCH=1: ONE launch -- the workgroup that takes the launch's last ticket adds up the row sums
+    (ddnerf_dp_loss_forward_kept1; the counter lives per device and stream, where launches are ordered); same bits, measured slower."""
     t1, t0, w1, w0, mus0, sig0, left0, part0 = (_f32c(t, "dp_loss arg") for t in (t1, t0, w1, w0, mus0, sig0, left0, part0))
     n, nc = w0.shape
     nf = w1.shape[1]

@@ -120,12 +120,12 @@ def test_fine_compositing_with_row_filter(ops, n, nc, nf, dp_blender):
         args = (t1, t0, c1["weights"], c0["weights"], head["mus"], head["sigmas"], head["left"], head["part"])
         loss_a, total_a = ops.dp_loss_forward(*args, dp_blender, reg_scal=head["scal"])
         c1b, ws = ops.composite_forward_keep(raw1, t1, rays, None, None, False, blender, dp_blender)
-        loss_b, total_b = ops.dp_loss_forward_kept(*args[:2], c1b["weights"], *args[3:], ws, head["scal"])    # (one launch: last-ticket finish)
-        ops.DP_ONE_LAUNCH = False
+        loss_b, total_b = ops.dp_loss_forward_kept(*args[:2], c1b["weights"], *args[3:], ws, head["scal"])    # rows kernel + finish kernel
+        ops.DP_ONE_LAUNCH = True
         try:
-            loss_c, total_c = ops.dp_loss_forward_kept(*args[:2], c1b["weights"], *args[3:], ws, head["scal"])   # rows kernel + finish kernel
+            loss_c, total_c = ops.dp_loss_forward_kept(*args[:2], c1b["weights"], *args[3:], ws, head["scal"])   # one launch: last-ticket finish
         finally:
-            ops.DP_ONE_LAUNCH = True
+            ops.DP_ONE_LAUNCH = False
         assert torch.equal(loss_b, loss_c) and torch.equal(total_b, total_c)
         for k in ("rgb_map", "disp", "acc", "weights", "depth"):
             a, b = c1[k], c1b[k]
@@ -279,11 +279,11 @@ def test_dp_loss_one_launch_many_times(ops):
         raw1 = (raw1[..., :4] + 0.1 * torch.randn(n, nf, 4, device="cuda", generator=g)).contiguous()
         c1, ws = ops.composite_forward_keep(raw1, t1, rays, None, None, False, True, True)
         args = (t1, t0, c1["weights"], c0["weights"], head["mus"], head["sigmas"], head["left"], head["part"])
-        a = ops.dp_loss_forward_kept(*args, ws, head["scal"])
-        ops.DP_ONE_LAUNCH = False
+        b = ops.dp_loss_forward_kept(*args, ws, head["scal"])
+        ops.DP_ONE_LAUNCH = True
         try:
-            b = ops.dp_loss_forward_kept(*args, ws, head["scal"])
+            a = ops.dp_loss_forward_kept(*args, ws, head["scal"])
         finally:
-            ops.DP_ONE_LAUNCH = True
+            ops.DP_ONE_LAUNCH = False
         bad += int(not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])))
     assert bad == 0, bad

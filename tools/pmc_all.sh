@@ -1,0 +1,14 @@
+#!/bin/bash
+# PMC evidence (MFMA utilisation, clocks, HBM bytes) for the MLP kernels; run on the GPU box from the repo root
+set -e
+R=${GRAFT_REPO_ROOT:?}; O=$R/gpurun_out/pmc; mkdir -p $O
+[ -f $R/tools/calib/calib.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC $R/tools/calib/calib.hip -o $R/tools/calib/calib.so
+cd /tmp; export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib -o c -- python3 $R/tools/calib/calib.py > $O/calib.log 2>&1
+for mlp in fp32 bf16 fp16 x3; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$mlp -o c -- python3 $R/bench.py --mlp $mlp --steps 4 --warmup 1 --no-cpu-baseline --no-bf16-tier --no-clock --ramp 0 > $O/fetch_$mlp.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$mlp -o c -- python3 $R/bench.py --mlp $mlp --steps 4 --warmup 1 --no-cpu-baseline --no-bf16-tier --no-clock --ramp 0 > $O/write_$mlp.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma_$mlp -o c -- python3 $R/bench.py --mlp $mlp --steps 4 --warmup 1 --no-cpu-baseline --no-bf16-tier --no-clock --ramp 0 > $O/mfma_$mlp.log 2>&1
+done
+echo done
+find $O -name "*kernel_trace.csv" -size +20M -delete
