@@ -47,13 +47,14 @@ def test_pack_rays_encode_mlp(ops, golden, name):
     assert maxerr(feat[:, :96], g["ipe"].reshape(-1, 96)) <= 4e-7   # vs the reference itself
     assert maxerr(feat[:, 96:123].reshape(g["rays"].shape[0], -1, 27)[:, 0], g["dirs"]) <= 2.4e-7
     # bf16 feature variant (columns in MFMA k-order): the fp32 feature rounded to nearest-even, except that its sin / exp come
-    # from the hardware transcendentals (absolute error ~1e-6): a few values per thousand sit on the other side of a bf16
-    # rounding boundary (one bf16 ulp), and values near zero differ by that absolute error
+    # from the hardware transcendentals (absolute error ~2e-6) and safe_sin's remainder from one fma (<= 2e-5, rays_encode.hip): a
+    # few values per hundred sit on the other side of a bf16 rounding boundary (one bf16 ulp), and values near zero differ by
+    # that absolute error
     fb = ops.encode(dev(g["rays"]), dev(g["t_vals"]), cylinder=cyl, bf16=True)
     want = torch.from_numpy(feat[:, ops.K_ORDER]).to(torch.bfloat16)
     diff = (fb.cpu().float() - want.float()).abs()
-    assert bool((diff <= want.float().abs() * 2.0 ** -7 + 4e-6).all()), float(diff.max())
-    assert float((fb.cpu() == want).float().mean()) >= 0.985
+    assert bool((diff <= want.float().abs() * 2.0 ** -7 + 3e-5).all()), float(diff.max())
+    assert float((fb.cpu() == want).float().mean()) >= 0.95
     # bf16-MFMA MLP: bf16 operands, fp32 accumulate -- its own tolerance tier
     for depth, seed, key in ((True, 11, "raw6"), (False, 12, "raw4")):
         sd = synthetic.make_state_dict(depth, seed)
