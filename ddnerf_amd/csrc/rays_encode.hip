@@ -316,19 +316,19 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
             damp[k] = BF16 ? fast_exp_neg(-0.5f * yv) : enc_exp_neg(-0.5f * yv);   // :149  (yv >= 0)
             ys[k] = y;
             yc[k] = y + 1.57079637f;                                          // :143  y + 0.5*fp32(pi)
-            if constexpr (BF16) {
-                // 16-bit rows: torch.remainder(x, T) as x - floor(x / T) T -- one fma, EXACT whenever the quotient is right (the true
+            if constexpr (KIND == 1) {
+                // bf16 rows (fp16 rows, the 1e-4 parity tier, keep the exact recipe): torch.remainder(x, T) as x - floor(x / T) T -- one fma, EXACT whenever the quotient is right (the true
                 // remainder is representable); a quotient off by one near a multiple of T, and |x| < T with x < 0 (where the reference
                 // leaves x alone), move the argument by T = 100 pi + 5.6e-6: 5.6e-6 in the sine; the reference's own rounding of its
-                // `fmod + T` for negative x (<= 1.5e-5) is not reproduced.  <= 2e-5 in all, 1/200 of a bf16 ulp at 1, 1/12 of fp16's
-                // half ulp -- and no compare, no branch: a third of the instructions of the exact recipe below.
+                // `fmod + T` for negative x (<= 1.5e-5) is not reproduced.  <= 2e-5 in all, 1/200 of a bf16 ulp at 1 -- and no compare,
+                // no branch: a third of the instructions of the exact recipe below.
                 ys[k] = __builtin_fmaf(-__builtin_floorf(ys[k] * 0.0031830988f), T, ys[k]);
                 yc[k] = __builtin_fmaf(-__builtin_floorf(yc[k] * 0.0031830988f), T, yc[k]);
             } else {
                 big |= !(fabsf(ys[k]) < T) || !(fabsf(yc[k]) < T);
             }
         }
-        if constexpr (!BF16) {
+        if constexpr (KIND != 1) {
             if (__builtin_amdgcn_ballot_w64(big) != 0) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
