@@ -236,9 +236,22 @@ __device__ __forceinline__ unsigned short f32_to_h16(float f) {
 #define ENC_SPB 32  // samples per 256-thread block (measured on the bf16 rows, fine / coarse pass: 16 -> 54 / 32 us, 32 -> 48 / 26, 64 -> 53 / 30)
 #endif
 
-template <int KIND>   // feature rows: 0 fp32 (natural column order), 1 bf16, 2 fp16 (both in MFMA k-order)
-__global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ rays, const float *__restrict__ t_vals,
-                                                     void *__restrict__ feat_, int n, int S, int cylinder) {
+// FIRST (the coarse pass of a ray batch that is one chunk, no first-cycle jitter): the launch ALSO packs the rays and samples the first
+// cycle -- a1 + a2, models/models.py:144-162 and models/samplers.py:30-62 -- from the raw origins / directions / radii: `rays` and `t_vals`
+// are then OUTPUTS (bit for bit pack_first_cycle_kernel's), written by the threads that need the values anyway, and the features come
+// from the same values.  One launch less at the head of every chunk.
+struct FirstCycle {
+    const float *ro, *rd, *rad, *t_lin;
+    float near_, far_;
+    int lindisp;
+};
+
+template <int KIND, bool FIRST>   // feature rows: 0 fp32 (natural column order), 1 bf16, 2 fp16 (both in MFMA k-order)
+__global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ rays_in, const float *__restrict__ t_vals_in,
+                                                     void *__restrict__ feat_, int n, int S, int cylinder, FirstCycle fc,
+                                                     float *__restrict__ rays_out, float *__restrict__ t_out) {
+    const float *__restrict__ rays = FIRST ? rays_out : rays_in;       // (FIRST: only this block's own writes are read back, see phase 1)
+    const float *__restrict__ t_vals = FIRST ? t_out : t_vals_in;
     __shared__ float g_mean[ENC_SPB][4];
     __shared__ float g_cov[ENC_SPB][4];
     __shared__ __attribute__((aligned(16))) float row[ENC_SPB][100];   // the IPE columns of the block's samples (stride 100: the 16
@@ -256,17 +269,45 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
         size_t m = m0 + ls;
         if (m < M) {
             int i = (int)(m / S), j = (int)(m % S);
-            const float *r = rays + 12 * (size_t)i;
-            const float *t = t_vals + (size_t)i * (S + 1) + j;
+            float t0v, t1v, rad_v, d0, d1, d2, oa;
+            if constexpr (FIRST) {
+                d0 = fc.rd[3 * (size_t)i];
+                d1 = fc.rd[3 * (size_t)i + 1];
+                d2 = fc.rd[3 * (size_t)i + 2];
+                rad_v = fc.rad[i];
+                oa = fc.ro[3 * (size_t)i + a];
+                t0v = first_cycle_t(fc.near_, fc.far_, fc.t_lin[j], fc.lindisp);
+                t1v = first_cycle_t(fc.near_, fc.far_, fc.t_lin[j + 1], fc.lindisp);
+                if (a == 0) {   // this sample's fencepost (and the ray's last one), the ray's packed row: pack_first_cycle_kernel's values
+                    t_out[(size_t)i * (S + 1) + j] = t0v;
+                    if (j == S - 1) t_out[(size_t)i * (S + 1) + S] = t1v;
+                    if (j == 0) {
+                        const float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+                        float *r = rays_out + 12 * (size_t)i;
+                        r[0] = fc.ro[3 * (size_t)i]; r[1] = fc.ro[3 * (size_t)i + 1]; r[2] = fc.ro[3 * (size_t)i + 2];
+                        r[3] = d0; r[4] = d1; r[5] = d2;
+                        r[6] = rad_v;
+                        r[7] = fc.near_; r[8] = fc.far_;
+                        r[9] = d0 / nrm; r[10] = d1 / nrm; r[11] = d2 / nrm;
+                    }
+                }
+            } else {
+                const float *r = rays + 12 * (size_t)i;
+                const float *t = t_vals + (size_t)i * (S + 1) + j;
+                t0v = t[0];
+                t1v = t[1];
+                rad_v = r[6];
+                d0 = r[3], d1 = r[4], d2 = r[5];
+                oa = r[a];
+            }
             float tm, tv, rv;
-            gaussian_of_interval(t[0], t[1], r[6], cylinder, tm, tv, rv);
-            float d0 = r[3], d1 = r[4], d2 = r[5];
+            gaussian_of_interval(t0v, t1v, rad_v, cylinder, tm, tv, rv);
             float q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
             float dmag = fmaxf(1e-10f, (q0 + q1) + q2);                       // :38
-            float da = r[3 + a], qa = da * da;
+            float da = a == 0 ? d0 : (a == 1 ? d1 : d2), qa = da * da;
             float nul = 1.0f - qa / dmag;                                     // :42
             if (a == 0) ray_of[ls] = i - (int)(m0 / S);
-            g_mean[ls][a] = da * tm + r[a];                                   // :36, :30
+            g_mean[ls][a] = da * tm + oa;                                     // :36, :30
             g_cov[ls][a] = tv * qa + rv * nul;                                // :43-45
         }
     }
@@ -280,7 +321,13 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
         for (int t2 = 255 - tid; t2 < nrays * 12; t2 += 256) {
             int lr = t2 / 12, k = t2 % 12;  // k: 0..11 -> (freq f = k/3, axis a = k%3), emits sin and cos
             int f = k / 3, a = k % 3;
-            float v = rays[12 * (size_t)(ray0 + lr) + 9 + a];
+            float v;
+            if constexpr (FIRST) {   // the packed row's unit direction d / ||d|| (pack_rays_kernel's arithmetic)
+                const float *dd = fc.rd + 3 * (size_t)(ray0 + lr);
+                v = dd[a] / sqrtf((dd[0] * dd[0] + dd[1] * dd[1]) + dd[2] * dd[2]);
+            } else {
+                v = rays[12 * (size_t)(ray0 + lr) + 9 + a];
+            }
             float x = v * (float)(1 << f);                                // nerf_helpers.py:163-165
             dirv[lr][3 + f * 6 + a] = BF16 ? fast_sin(x) : enc_sin(x);                       // |x| <= 8
             dirv[lr][3 + f * 6 + 3 + a] = BF16 ? fast_sin(x + 1.57079637f) : enc_sin(x, 1);  // cos
@@ -387,11 +434,42 @@ DDN_EXPORT int ddnerf_encode(const float *rays, const float *t_vals, void *feat,
     DDN_REQUIRE(ddn_aligned(feat, 16), DDNERF_E_ALIGN);
     size_t M = (size_t)n * S;
     dim3 grid((unsigned)((M + ENC_SPB - 1) / ENC_SPB));
+    const FirstCycle none{};
     if (feat_dtype == 0)
-        hipLaunchKernelGGL(encode_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape);
+        hipLaunchKernelGGL((encode_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape, none,
+                           (float *)nullptr, (float *)nullptr);
     else if (feat_dtype == 1)
-        hipLaunchKernelGGL(encode_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape);
+        hipLaunchKernelGGL((encode_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape, none,
+                           (float *)nullptr, (float *)nullptr);
     else
-        hipLaunchKernelGGL(encode_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape);
+        hipLaunchKernelGGL((encode_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape, none,
+                           (float *)nullptr, (float *)nullptr);
+    return ddn_launch_status();
+}
+
+// a1 + a2 + (a3 + a4 + a5) in ONE launch: ddnerf_pack_rays_first_cycle without jitter (t_rand == NULL) followed by ddnerf_encode of its
+// outputs -- rays [n,12] and t_vals [n,nc+1] are written, feat [n*nc,128] is the encoding of exactly those values (bit for bit the two
+// entry points' outputs).  lindisp as ddnerf_pack_rays_first_cycle.
+DDN_EXPORT int ddnerf_encode_first_cycle(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                                         const float *t_lin, int lindisp, float *rays, float *t_vals, void *feat, int n, int nc,
+                                         int ray_shape, int feat_dtype, ddnerf_stream_t stream) {
+    DDN_REQUIRE(origins && directions && radii && t_lin && rays && t_vals && feat, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ray_shape == 0 || ray_shape == 1, DDNERF_E_RANGE);
+    DDN_REQUIRE(lindisp >= 0 && lindisp <= 2, DDNERF_E_RANGE);
+    DDN_REQUIRE(feat_dtype >= 0 && feat_dtype <= 2, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(feat, 16), DDNERF_E_ALIGN);
+    size_t M = (size_t)n * nc;
+    dim3 grid((unsigned)((M + ENC_SPB - 1) / ENC_SPB));
+    const FirstCycle fc{origins, directions, radii, t_lin, near_, far_, lindisp};
+    if (feat_dtype == 0)
+        hipLaunchKernelGGL((encode_kernel<0, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, (const float *)nullptr, feat,
+                           n, nc, ray_shape, fc, rays, t_vals);
+    else if (feat_dtype == 1)
+        hipLaunchKernelGGL((encode_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, (const float *)nullptr, feat,
+                           n, nc, ray_shape, fc, rays, t_vals);
+    else
+        hipLaunchKernelGGL((encode_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, (const float *)nullptr, feat,
+                           n, nc, ray_shape, fc, rays, t_vals);
     return ddn_launch_status();
 }

@@ -120,7 +120,7 @@ class GeneralMipNerfModel(torch.nn.Module):
         """models/models.py:40-73"""
         shape_rgb = ray_directions.shape
         shape_depth = ray_directions.shape[:-1]
-        batches = self.get_rays_batches(ray_origins, ray_directions, ray_rad, mode)
+        batches = self.get_rays_batches(ray_origins, ray_directions, ray_rad, mode, _defer=True)
         if rgb_target is not None:
             rgb_targets = get_minibatches(rgb_target.reshape(-1, 3), chunksize=getattr(self.cfg.nerf, mode).chunksize)
         else:
@@ -152,18 +152,28 @@ class GeneralMipNerfModel(torch.nn.Module):
                     output[i]["corrected_disp_map"] = output[i]["corrected_disp_map"].view(shape_depth)
         return output
 
-    def get_rays_batches(self, ray_origins, ray_directions, ray_rad, mode):
+    def get_rays_batches(self, ray_origins, ray_directions, ray_rad, mode, _defer=False):
         """models/models.py:144-162 (K0 pack kernel, then views of <= chunksize rays)"""
         self._t0_ready = None
+        self._first_pending = None
         mc = self._mode_cfg(mode)
         n = ray_directions.numel() // 3
         if (FUSE_RENDER and n <= mc.chunksize and not mc.perturb and not self.cfg.dataset.get("combined_sampling_method", False)):
-            # ONE chunk and no jitter draw: the packed rows and the first-cycle fenceposts come out of one launch (the same
-            # arithmetic as the two kernels); predict picks the fenceposts up instead of launching sample_first_cycle
+            # ONE chunk and no jitter draw: the packed rows and the first-cycle fenceposts are written by the launch that ENCODES the
+            # coarse samples (ops.encode_first_cycle, run_network below: the same arithmetic as pack_rays + sample_first_cycle + encode,
+            # one launch instead of three).  The two tensors are handed out here and filled there: everything that reads them is
+            # enqueued behind that launch (predict's first step is run_network on exactly this batch).
             t_lin = _host_const("linspace", 0.0, 1.0, mc.num_coarse + 1, ray_directions.device)
-            rays, t0 = ops.pack_rays_first_cycle(ray_origins, ray_directions, ray_rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin,
-                                                 None, bool(mc.lindisp))
+            if not _defer:   # (a caller other than run_iter gets the rows filled: pack + first cycle in their own launch)
+                rays, t0 = ops.pack_rays_first_cycle(ray_origins, ray_directions, ray_rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin,
+                                                     None, bool(mc.lindisp))
+                self._t0_ready = (rays.data_ptr(), t0)
+                return [rays]
+            dev = ray_directions.device
+            rays = torch.empty((n, 12), dtype=torch.float32, device=dev)
+            t0 = torch.empty((n, mc.num_coarse + 1), dtype=torch.float32, device=dev)
             self._t0_ready = (rays.data_ptr(), t0)
+            self._first_pending = (rays, t0, ray_origins, ray_directions, ray_rad, t_lin, bool(mc.lindisp))
             return [rays]
         rays = ops.pack_rays(ray_origins, ray_directions, ray_rad, self.cfg.dataset.near, self.cfg.dataset.far)
         return get_minibatches(rays, chunksize=getattr(self.cfg.nerf, mode).chunksize)
@@ -222,6 +232,15 @@ class GeneralMipNerfModel(torch.nn.Module):
             scaled = getattr(self.rng, "randn_scaled", None)
             return scaled((n, S), device, std) if scaled is not None else self.rng.randn((n, S), device) * std
         return None
+
+    def _flush_first_pending(self):
+        """fill the ray rows / fenceposts get_rays_batches handed out, without encoding (they were not the next thing encoded)"""
+        pend, self._first_pending = getattr(self, "_first_pending", None), None
+        if pend is not None:
+            rays, t0, ro, rd, rad, t_lin, lindisp = pend
+            r2, t2 = ops.pack_rays_first_cycle(ro, rd, rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin, None, lindisp)
+            rays.copy_(r2)
+            t0.copy_(t2)
 
     def run_network(self, ray_batch, t_vals, network, mode):
         """models/models.py:117-142: encode (K1) + fused MLP (K2); [n,S,4|6]"""

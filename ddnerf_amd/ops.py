@@ -318,6 +318,24 @@ def pack_rays_first_cycle(ray_origins, ray_directions, ray_rad, near, far, t_lin
     return rays, t_vals
 
 
+def encode_first_cycle(ray_origins, ray_directions, ray_rad, near, far, t_lin, lindisp=False, cylinder=False, kind="fp32", out=None):
+    """pack_rays_first_cycle (no jitter) + encode of the coarse fenceposts in ONE launch -> (rays [n,12], t_vals [n,nc+1], feat [n*nc,128]);
+    `out` = (rays, t_vals) tensors to fill (the caller handed them out earlier, see GeneralMipNerfModel.get_rays_batches)"""
+    o = _f32c(ray_origins.reshape(-1, 3), "origins")
+    d = _f32c(ray_directions.reshape(-1, 3), "directions")
+    r = _f32c(ray_rad.reshape(-1), "radii")
+    t_lin = _f32c(t_lin, "t_lin")
+    n, nc = o.shape[0], t_lin.shape[0] - 1
+    if out is None:
+        out = (torch.empty((n, 12), dtype=torch.float32, device=o.device), torch.empty((n, nc + 1), dtype=torch.float32, device=o.device))
+    rays, t_vals = out
+    code, dtype = FEAT_KINDS[kind]
+    feat = torch.empty((n * nc, FEAT_LD), dtype=dtype, device=o.device)
+    _lib.check(_lib.lib().ddnerf_encode_first_cycle(_ptr(o), _ptr(d), _ptr(r), float(near), float(far), _ptr(t_lin), int(lindisp), _ptr(rays),
+                                                    _ptr(t_vals), _ptr(feat), n, nc, int(cylinder), code, _stream()), "ddnerf_encode_first_cycle")
+    return rays, t_vals, feat
+
+
 class KernelNoise:
     """density noise the compositing kernels draw themselves (volume_rendering_utils.py:29-37's randn * std without a generator launch or a
     noise tensor): (seed, offset) of the Philox stream, `base` = the first element index of this pass, `std`"""

@@ -77,6 +77,12 @@ int ddnerf_pack_rays_first_cycle(const float *origins, const float *directions, 
  * order), 1 bf16, 2 fp16 (both with the columns in MFMA k-order, see ddnerf_mlp_bf16_forward / ddnerf_mlp_f16_forward). */
 int ddnerf_encode(const float *rays, const float *t_vals, void *feat, int n, int S, int ray_shape, int feat_dtype,
                   ddnerf_stream_t stream);
+/* a1 + a2 + (a3 + a4 + a5) in ONE launch for a ray batch that is a single chunk with no first-cycle jitter: ddnerf_pack_rays_first_cycle
+ * (t_rand == NULL) followed by ddnerf_encode of its outputs.  rays [n,12] and t_vals [n,nc+1] are OUTPUTS (bit for bit that entry point's),
+ * feat [n*nc,128] is the encoding of exactly those values. */
+int ddnerf_encode_first_cycle(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                              const float *t_lin, int lindisp, float *rays, float *t_vals, void *feat, int n, int nc, int ray_shape,
+                              int feat_dtype, ddnerf_stream_t stream);
 
 /* a7  MipNeRFModel.forward / DepthMipNeRFModel.forward  models/base_architectures.py:40-61, 103-126
  * as ONE fused kernel (all 12/13 Linear layers, activations never leave the register file).

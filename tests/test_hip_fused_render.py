@@ -38,6 +38,23 @@ def test_pack_rays_first_cycle(ops, n, nc, lindisp):
         assert torch.equal(rays_a, rays_b) and torch.equal(t_a, t_b)
 
 
+@pytest.mark.parametrize("kind", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("lindisp,cyl", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("n,nc", [(1, 4), (37, 64), (4096, 64), (300, 33), (5, 128)])
+def test_encode_first_cycle(ops, n, nc, lindisp, cyl, kind):
+    """pack + first cycle + coarse encode in one launch: rays, fenceposts and features bit for bit those of the separate launches (a block
+    of 32 samples straddles rays when nc is not a multiple of 32; the last fencepost of a ray is written by its last sample's thread)"""
+    ro, rd, rad = _rays("real360" if lindisp else "blender", n, 5)
+    near, far = (0.2, 2.8) if lindisp else (2.0, 6.0)
+    t_lin = torch.linspace(0.0, 1.0, nc + 1).cuda()
+    rays_a, t_a = ops.pack_rays_first_cycle(ro, rd, rad, near, far, t_lin, None, lindisp)
+    feat_a = ops.encode(rays_a, t_a, cylinder=cyl, kind=kind)
+    rays_b, t_b, feat_b = ops.encode_first_cycle(ro, rd, rad, near, far, t_lin, lindisp, cylinder=cyl, kind=kind)
+    assert torch.equal(rays_a, rays_b) and torch.equal(t_a, t_b)
+    assert feat_a.dtype == feat_b.dtype and torch.equal(feat_a.view(torch.int16 if kind != "fp32" else torch.int32),
+                                                        feat_b.view(torch.int16 if kind != "fp32" else torch.int32))
+
+
 def _coarse_inputs(n, nc, seed, kind="blender", zero_rows=False):
     g = torch.Generator(device="cuda").manual_seed(seed)
     ro, rd, rad = _rays(kind, n, seed)
