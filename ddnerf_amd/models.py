@@ -136,6 +136,7 @@ class GeneralMipNerfModel(torch.nn.Module):
                 finish()
         finally:
             self._deferred_records = None
+            self._flush_first_pending()    # (no-op: predict's first run_network filled the packed rows it was handed)
         output = pred[0]
         if len(pred) > 1:
             for j in range(len(output)):
@@ -248,7 +249,17 @@ class GeneralMipNerfModel(torch.nn.Module):
         shape = str(self.cfg.nerf.ray_shape)
         if shape not in ("cone", "cylinder"):
             raise AssertionError("ray_shape must be 'cone' or 'cylinder'")  # math_utils.py:28
-        feat = ops.encode(ray_batch, t_vals, cylinder=(shape == "cylinder"), kind=kind)
+        pend = getattr(self, "_first_pending", None)
+        if pend is not None and pend[0].data_ptr() == ray_batch.data_ptr() and pend[1].data_ptr() == t_vals.data_ptr():
+            # the coarse pass of a one-chunk batch: this launch also fills ray_batch and t_vals (get_rays_batches handed them out empty)
+            self._first_pending = None
+            rays, t0, ro, rd, rad, t_lin, lindisp = pend
+            feat = ops.encode_first_cycle(ro, rd, rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin, lindisp,
+                                          cylinder=(shape == "cylinder"), kind=kind, out=(rays, t0))[2]
+        else:
+            if pend is not None:     # (something else is encoded first: fill the pending tensors the plain way)
+                self._flush_first_pending()
+            feat = ops.encode(ray_batch, t_vals, cylinder=(shape == "cylinder"), kind=kind)
         raw = F.mlp(feat, network)
         return raw.reshape(t_vals.shape[0], t_vals.shape[1] - 1, raw.shape[-1])
 
