@@ -303,7 +303,7 @@ def image_tier(args, mlp, size="800x800"):
     return im
 
 
-def cpu_baseline(args, cfg, sd_c, sd_f):
+def cpu_baseline(args, cfg, sd_c, sd_f, check_model=None):
     """The CPU oracle (a C port of the reference path, oracle/) on a bounded sample of the same workload."""
     import numpy as np
     import torch
@@ -336,13 +336,44 @@ def cpu_baseline(args, cfg, sd_c, sd_f):
         O.run_iter(ro, rd, rad, sd_c, sd_f, **kw)
         return time.perf_counter() - t0
 
+    parity = None
+    if check_model is not None:
+        # the path that was just timed against the CPU oracle, noise off, 64 rays of the same kind: the line is self-validating (a
+        # render that runs fast and computes something else is not a number)
+        import torch as _t
+
+        n0 = 64
+        ro, rd, rad, _ = synthetic.make_rays(args.ray_kind, n0, 99)
+        kw = dict(model="dd" if dd else "mip", nc=args.coarse, nf=args.fine, near=float(cfg.dataset.near), far=float(cfg.dataset.far),
+                  blender=is_blender, white_bkgd=bool(mc.white_background), lindisp=bool(mc.lindisp),
+                  pdf_padding=bool(cfg.train_params.pdf_padding), smooth=float(cfg.train_params.gaussian_smooth_factor),
+                  dist_reg=float(cfg.train_params.dist_reg_coeficient), t_lin=t_lin, u_det=u_det)
+        want = O.run_iter(ro, rd, rad, sd_c, sd_f, **kw)
+        std = {m: cfg.nerf[m]["radiance_field_noise_std"] for m in ("train", "validation")}
+        try:
+            for m in std:
+                cfg.nerf[m]["radiance_field_noise_std"] = 0.0
+            dev = next(check_model.coarse.parameters()).device
+            with _t.no_grad():
+                got = check_model.run_iter(*(_t.from_numpy(x).to(dev) for x in (ro, rd, rad)), mode="validation")
+        finally:
+            for m in std:
+                cfg.nerf[m]["radiance_field_noise_std"] = std[m]
+        errs = {"L%d_%s" % (lvl, k): float(np.abs(got[lvl][k].reshape(want[lvl][k].shape).cpu().numpy() - want[lvl][k]).max())
+                for lvl in (0, 1) for k in ("rgb", "depth")}
+        parity = {"rays": n0, "noise": "off", "max_abs_err_vs_cpu_oracle": {k: float("%.3g" % v) for k, v in errs.items()},
+                  "within_1e-4": bool(max(errs.values()) <= 1e-4)}
+
     run(64)                                  # warm-up (thread pool, page faults)
     probe = run(args.cpu_rays)               # calibrate, then size the sample for ~15 s of CPU work
     n = int(min(max(args.cpu_rays, args.cpu_rays * 15.0 / max(probe, 1e-3)), 65536)) // 256 * 256
     dt = run(n)
-    return {"value": n / dt, "unit": "rays/s", "cores": O.get_threads(), "kind": "port",
-            "sample": "%s, %d %s rays x (%d+%d) samples, render pass, C oracle with OpenMP, %.1f s"
-                      % (args.config, n, args.ray_kind, args.coarse, args.fine, dt)}
+    out = {"value": n / dt, "unit": "rays/s", "cores": O.get_threads(), "kind": "port",
+           "sample": "%s, %d %s rays x (%d+%d) samples, render pass, C / OpenMP port of the reference path (oracle/), %.1f s"
+                     % (args.config, n, args.ray_kind, args.coarse, args.fine, dt)}
+    if parity is not None:
+        out["parity_check"] = parity
+    return out
 
 
 def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
@@ -590,7 +621,7 @@ def main(argv=None):
                              "roofline": train_roofline(args, cfg, tdt / args.steps)}
         line.update(tiers)
         if world == 1 and not args.no_cpu_baseline and head == "render":
-            line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f)
+            line["cpu_baseline"] = cpu_baseline(args, cfg, sd_c, sd_f, check_model=model)
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
     if dist:
