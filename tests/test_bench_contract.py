@@ -45,8 +45,22 @@ def test_render_line_has_the_contract_fields():
     assert 1000 < clk["in_kernel_clock_mhz"] <= 2500 and 0.5 < clk["mfma_busy"] <= 1.0
     assert abs(clk["mfma_busy"] - clk["ideal_cycles_per_tile"] / clk["cycles_per_tile"]) < 1e-3
     tt = d["train_tier"]
-    assert tt["x3"]["value"] > tt["fp32"]["value"] > 0
+    assert tt["x3"]["value"] > tt["x3_exact"]["value"] > tt["fp32_pairs"]["value"] > tt["fp32"]["value"] > 0
     assert tt["x3"]["roofline"]["frac"] < tt["x3"]["roofline"]["frac_issued"] < 3 * tt["x3"]["roofline"]["frac"]
+    assert "NOT fp32-class" in tt["fp32_pairs"]["dtype"] and "fp32-class" in tt["x3_exact"]["dtype"]
+    # round 4: the fp16 tier; the same-box bare-loop ceiling beside the bf16 fraction; the image-level figure; the self-check of the
+    # timed path against the CPU oracle
+    f16 = d["fp16_tier"]
+    assert f16["value"] > 2 * d["x3_tier"]["value"] and 0.3 < f16["roofline"]["frac"] < 1.0 and "fp16" in f16["dtype"]
+    ceil = d["bf16_tier"]["roofline"]["ceiling_same_box"]
+    assert 0.5 < ceil["lds_fed_staged"]["frac"] <= ceil["lds_fed"]["frac"] + 0.03 and ceil["lds_fed"]["frac"] <= ceil["registers"]["frac"] + 0.03 < 1.03
+    assert abs(ceil["kernel_frac_over_staged_ceiling"] - d["bf16_tier"]["roofline"]["frac"] / ceil["lds_fed_staged"]["frac"]) < 2e-3
+    assert d["roofline"]["traffic_measured_in_run"] is False
+    for tier in ("fp32", "fp16", "bf16"):
+        im = d["image"][tier]
+        assert im["size"] == "800x800" and im["chunks"] == 40 and im["rays_per_s"] > 0 and 0.9 <= im["image_over_chunk_rate"] <= 1.1, (tier, im)
+    pc = c["parity_check"]
+    assert pc["within_1e-4"] is True and max(pc["max_abs_err_vs_cpu_oracle"].values()) <= 1e-4, pc
 
 
 def test_train_line():
