@@ -107,3 +107,24 @@ def test_image_level_number():
     assert im["size"] == "400x400" and im["rays"] == 160000 and im["chunks"] == 10 and im["rgb_shape"] == [400, 400, 3]
     assert abs(im["rays_per_s"] - 160000 / im["s_per_image"]) <= 1e-2 * im["rays_per_s"]
     assert im["rays_per_s"] >= 0.9 * d["value"], (im, d["value"])
+
+
+def test_two_ranks_under_torch_distributed_run_on_one_gpu():
+    """the driver's N > 1 command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with N = 2 ranks sharing the box's one GPU over gloo: bench.py must take RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the launcher's environment (not start ranks of its own) and rank 0 must print exactly one JSON line"""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--share-gpu", "--rays", "1024", "--mlp", "x3"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["global_rays"] == 2048 and d["train"]["value"] > 0
