@@ -123,6 +123,9 @@ DDN_EXPORT int ddnerf_mlp_f32_pack(const float *params, int depth_head, float *p
     return ddn_launch_status();
 }
 
+#ifdef F32_STAMP_TILE
+__device__ unsigned long long g_f32_tile[4096 * 6];
+#endif
 #ifdef F32_STAMP
 // Diagnostic build (tools/f32_clock.py): eight clock stamps per slice, held in scalar registers (one s_memtime each, nothing waits on
 // them inside the slice) and written out by thread 0 of every 64th workgroup behind the slice's last MFMA.
@@ -316,6 +319,10 @@ __device__ __forceinline__ void load_features(const float *__restrict__ frow, in
     }
 }
 
+// Persistent (round 4): one workgroup per CU walks the 128-sample tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The only exposed
+// fetches are the first tile's: every later tile finds its slice 0 in LDS (fetched under the head layer of the tile before, whose
+// "next slice" wraps to the buffer's start), its first fragments and bias tile in registers, and its xyz features in Breg[8..10]
+// (fetched under layers_dir).  A workgroup per tile paid 1.7 % of the launch between workgroups and 0.3 % in the prologue.
 template <bool DEPTH>
 __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_kernel(const float *__restrict__ feat,
                                                              const float *__restrict__ packed, PackPlan pl,
@@ -326,88 +333,123 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_kernel(const float *__rest
     float *scr_wave = lds + 2 * MAX_SLICE_FLOATS + SCR_FLOATS * wave;  // this wave's ReLU scratch (relu_push / _pull / _rezero)
 #pragma unroll
     for (int k = 0; k < 4; ++k) relu_rezero(scr_wave, lane, k);
-    const long m = (long)blockIdx.x * 128 + wave * 32 + j;
-    const bool valid = m < M;
-    const float *frow = feat + (size_t)(valid ? m : M - 1) * DDNERF_FEAT_LD;
+    const long ntiles = (M + 127) / 128;
+    // row of this lane's sample in tile t (clamped: lanes past the end compute on the last sample and store nothing)
+    auto feat_row = [&](long t) {
+        const long mm = t * 128 + wave * 32 + j;
+        return feat + (size_t)(mm < M ? mm : M - 1) * DDNERF_FEAT_LD;
+    };
 
     f32x16 Breg[12];
     f32x16 out[8];
 #ifdef F32_STAMP
     if (tid == 0) f32_stamp_idx = 0;
 #endif
+#ifdef F32_STAMP_TILE   // (diagnostic build: first and last instruction of every workgroup on the shader clock and on the 100 MHz clock)
+    const unsigned long long tile_t0 = __builtin_amdgcn_s_memtime(), tile_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tile_t1 = 0;
+#endif
 
-    // stage slice 0 synchronously, fetch the sample's 128 features into B layout meanwhile
-    const float *wp = packed;
+    // first tile only: stage slice 0 synchronously, fetch the sample's xyz features into B layout meanwhile
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)packed, 0, 4 * pl.bias_off[0], 0x00020000);  // the slices
-    unsigned woff = 0;
     {
         constexpr int ROUNDS = slice_floats(96) / 1024;
         f32x4 pf[ROUNDS];
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(wp + 4 * (size_t)(r * 256 + tid));
-        load_features<8, 0, 3>(frow, h, Breg);  // xyz features; dead again after layer 0
+        for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(packed + 4 * (size_t)(r * 256 + tid));
+        load_features<8, 0, 3>(feat_row(blockIdx.x), h, Breg);  // xyz features; dead again after layer 0
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(lds + 4 * (r * 256 + tid)) = pf[r];
     }
     __syncthreads();
-
-    f32x16 bcur = lds_bias_tile(lds + 32 * (96 + 4), h);  // the only exposed bias and fragment reads of the tile
+#ifdef F32_STAMP_TILE
+    tile_t1 = __builtin_amdgcn_s_memtime();
+#endif
+    f32x16 bcur = lds_bias_tile(lds + 32 * (96 + 4), h);  // the only exposed bias and fragment reads of the workgroup
     f32x4 carry[2];
     carry[0] = *(const f32x4 *)(lds + j * (96 + 4) + 4 * h);
     carry[1] = *(const f32x4 *)(lds + j * (96 + 4) + 4 * h + 8);
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long m = tile * 128 + wave * 32 + j;
+        const bool valid = m < M;
+        const float *frow = feat_row(tile);
+        unsigned woff = 0;
 #define NEXT_LAYER()                                  \
     _Pragma("unroll") for (int b = 0; b < 8; ++b) Breg[b] = out[b];
-    // (straight-line: the output tiles of one layer ARE the B operands of the next -- a loop would copy 128 registers per trip)
-    // layer 0: 96 -> 256, ReLU                                             base_architectures.py:42-43
-    layer<0, 96, 8, 256, 0, 8, false>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    // layers 1..4: 256 -> 256, ReLU                                        :44-49
-    layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    layer<1, 256, 8, 352, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    // layer 5: cat(xyz, x) 352 -> 256, ReLU                                :45-46
-    load_features<8, 0, 3>(frow, h, Breg);  // re-fetched (L2) instead of held in 48 registers across layers 1-4
-    __builtin_amdgcn_sched_barrier(0);
-    layer<2, 352, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    // layers 6, 7 (ReLU) and fc_feat (no activation)                       :47-50
-    layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    layer<1, 256, 8, 288, 0, 0, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    NEXT_LAYER();
-    // layers_dir.0 on cat(feat, dirs) + fc_alpha on feat: 288 -> 160       :51-56
-    load_features<11, 3, 1>(frow, h, Breg);  // view-dir columns 96..127
-    __builtin_amdgcn_sched_barrier(0);
-    layer<3, 288, 5, 128, 0, 4>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
-    const float alpha = out[4][0];  // row 128 = block 4, register 0, lane half 0 (tile 4 carries no ReLU)
+        // (straight-line: the output tiles of one layer ARE the B operands of the next -- a loop would copy 128 registers per trip)
+        // layer 0: 96 -> 256, ReLU                                             base_architectures.py:42-43
+        layer<0, 96, 8, 256, 0, 8, false>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        // layers 1..4: 256 -> 256, ReLU                                        :44-49
+        layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        layer<1, 256, 8, 352, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        // layer 5: cat(xyz, x) 352 -> 256, ReLU                                :45-46
+        load_features<8, 0, 3>(frow, h, Breg);  // re-fetched (L2) instead of held in 48 registers across layers 1-4
+        __builtin_amdgcn_sched_barrier(0);
+        layer<2, 352, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        // layers 6, 7 (ReLU) and fc_feat (no activation)                       :47-50
+        layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        layer<1, 256, 8, 256, 0, 8, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        layer<1, 256, 8, 288, 0, 0, true>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        NEXT_LAYER();
+        // layers_dir.0 on cat(feat, dirs) + fc_alpha on feat: 288 -> 160       :51-56
+        load_features<11, 3, 1>(frow, h, Breg);  // view-dir columns 96..127
+        load_features<8, 0, 3>(feat_row(tile + gridDim.x < ntiles ? tile + gridDim.x : tile), h, Breg);  // the NEXT tile's xyz features
+        __builtin_amdgcn_sched_barrier(0);
+        layer<3, 288, 5, 128, 0, 4>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        const float alpha = out[4][0];  // row 128 = block 4, register 0, lane half 0 (tile 4 carries no ReLU)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) Breg[b] = out[b];
-    // fc_rgb (+ fc_mu_sigma): 128 -> 32 rows                               :60 / :123-124
-    layer<4, 128, 1, 0, 1, 0>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
+        for (int b = 0; b < 4; ++b) Breg[b] = out[b];
+        // fc_rgb (+ fc_mu_sigma): 128 -> 32 rows; its "next slice" is slice 0 again, for the next tile      :60 / :123-124
+        woff = 0u - 4096u * (slice_floats(128) / 1024);
+        layer<4, 128, 1, 96, 1, 0>(wsrc, woff, lds, scr_wave, Breg, out, bcur, carry, tid, lane);
 #undef NEXT_LAYER
 
-    if (valid) {
-        if (DEPTH) {
-            float *o = raw + (size_t)m * 6;
-            if (h == 0) {
-                *(float2 *)(o) = make_float2(out[0][0], out[0][1]);
-                *(float2 *)(o + 2) = make_float2(out[0][2], alpha);
-            } else {
-                *(float2 *)(o + 4) = make_float2(out[0][0], out[0][1]);  // rows 4, 5 = raw mu, raw sigma
+        if (valid) {
+            if (DEPTH) {
+                float *o = raw + (size_t)m * 6;
+                if (h == 0) {
+                    *(float2 *)(o) = make_float2(out[0][0], out[0][1]);
+                    *(float2 *)(o + 2) = make_float2(out[0][2], alpha);
+                } else {
+                    *(float2 *)(o + 4) = make_float2(out[0][0], out[0][1]);  // rows 4, 5 = raw mu, raw sigma
+                }
+            } else if (h == 0) {
+                *(f32x4 *)(raw + (size_t)m * 4) = f32x4{out[0][0], out[0][1], out[0][2], alpha};
             }
-        } else if (h == 0) {
-            *(f32x4 *)(raw + (size_t)m * 4) = f32x4{out[0][0], out[0][1], out[0][2], alpha};
         }
     }
+#ifdef F32_STAMP_TILE
+    {
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();   // (behind the last MFMA's issue and the store's issue)
+        if (tid == 0 && blockIdx.x < 4096) {
+            unsigned long long *o = g_f32_tile + 6 * blockIdx.x;
+            o[0] = tile_t0;
+            o[1] = tile_t1;
+            o[2] = t2;
+            o[3] = tile_r0;
+            o[4] = __builtin_amdgcn_s_memrealtime();
+            o[5] = 0;
+        }
+    }
+#endif
 }
 
+#ifdef F32_STAMP_TILE
+DDN_EXPORT int ddnerf_debug_f32_tile_stamps(unsigned long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_tile), sizeof(g_f32_tile));
+}
+#endif
 #ifdef F32_STAMP
 DDN_EXPORT int ddnerf_debug_f32_stamps(unsigned long long *host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps), sizeof(g_f32_stamps));
@@ -420,7 +462,8 @@ DDN_EXPORT int ddnerf_mlp_f32_forward(const float *feat, const float *packed, in
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16), DDNERF_E_ALIGN);
     PackPlan pl = make_plan(depth_head);
-    dim3 grid((unsigned)((M + 127) / 128));
+    const long ntiles = (M + 127) / 128, cus = ddn_cu_count();
+    dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));   // persistent: the kernel needs a CU's whole register file and most of its LDS
     if (depth_head)
         hipLaunchKernelGGL(mlp_f32_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, pl, raw, M);
     else

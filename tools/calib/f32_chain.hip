@@ -4,6 +4,7 @@
 //     0 nothing   1 one v_accvgpr_read of ANOTHER accumulator tile   2 one VGPR->VGPR v_max_i32   3 read + max (the kernel's ReLU of one element)
 //     4 two reads + two max   5 v_accvgpr_read + v_max_i32 + v_accvgpr_write back   6 one ds_read_b128   7 MFMA B operand from an AGPR
 //     8 s_mov_b32   9 s_nop 0   10 s_waitcnt lgkmcnt(0)   11 buffer-less global_load_dwordx4   12 ds_write_b32
+//     16 global_load_lds_dwordx4 (LDS-DMA)   17 global_load_dword   18 global_load_dwordx4 with scalar base   19 the same behind every 2nd MFMA
 //     13 one v_max_i32 behind every 8th MFMA only   14 sixteen v_max_i32 behind every 8th MFMA   15 thirty-two behind every 8th
 //  two<MODE>:   two INDEPENDENT chains (a[0:15], a[16:31]) alternating; MODE 0 nothing, 2 one v_max_i32 behind each MFMA, 4 four
 //  swtch<N>:    chains of 8 MFMAs on alternating accumulators (a slice boundary every 8 MFMAs), N v_max_i32 AT the boundary
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256, 1) void side_kernel(float *out, int iters, uns
 #define INIT(n) asm volatile("v_accvgpr_write_b32 a" #n ", %0" ::"v"(0.0f));
     INIT(0) INIT(1) INIT(2) INIT(3) INIT(4) INIT(5) INIT(6) INIT(7) INIT(8) INIT(9) INIT(10) INIT(11) INIT(12) INIT(13) INIT(14) INIT(15)
     INIT(16) INIT(17) INIT(18) INIT(19) INIT(20) INIT(21) INIT(22) INIT(23)
+    asm volatile("s_mov_b32 m0, %0" ::"s"(2048u));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -61,6 +63,10 @@ __global__ __launch_bounds__(256, 1) void side_kernel(float *out, int iters, uns
             if (MODE == 9) asm volatile("s_nop 0");
             if (MODE == 10) asm volatile("s_waitcnt lgkmcnt(0)");
             if (MODE == 11) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dsv) : "v"(out + (threadIdx.x & 63) * 4));
+            if (MODE == 16) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(laddr), "s"(out) : "memory");
+            if (MODE == 17) asm volatile("global_load_dword %0, %1, off" : "=v"(dsv.x) : "v"(out + (threadIdx.x & 63)));
+            if (MODE == 18) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dsv) : "v"(laddr), "s"(out));
+            if (MODE == 19 && s % 2 == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dsv) : "v"(laddr), "s"(out));
             if (MODE == 12) asm volatile("ds_write_b32 %0, %1" ::"v"(laddr), "v"(x0));
             if (MODE == 13 && s % 8 == 7) asm volatile("v_max_i32 %0, 0, %1" : "=v"(y0) : "v"(x0));
             if ((MODE == 14 || MODE == 15) && s % 8 == 7) {
@@ -113,6 +119,36 @@ __global__ __launch_bounds__(256, 1) void two_kernel(float *out, int iters, unsi
     if (threadIdx.x == 0) stamps[blockIdx.x] = t1 - t0;
 }
 
+// Other MFMA shapes: KIND 0 v_mfma_f32_16x16x4_f32 (8 passes), 1 v_mfma_f32_16x16x32_bf16 (4 passes... see the cycles), 2 v_mfma_f32_32x32x16_bf16;
+// NV v_max_i32 behind every MFMA, the MFMAs rotating over NACC independent accumulators.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+template <int KIND, int NACC, int NV>
+__global__ __launch_bounds__(256, 1) void shape_kernel(float *out, int iters, unsigned long long *stamps) {
+    f32x4v acc4[NACC] = {};
+    f32x16 acc16[NACC] = {};
+    float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f + threadIdx.x * 1e-4f;
+    bf16x8v ha, hb;
+    for (int i = 0; i < 8; ++i) ha[i] = (__bf16)(a + i), hb[i] = (__bf16)(b + i);
+    float x0 = a, y0 = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            if (KIND == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc4[s % NACC]) : "v"(a), "v"(b));
+            if (KIND == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc4[s % NACC]) : "v"(ha), "v"(hb));
+            if (KIND == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc16[s % NACC]) : "v"(ha), "v"(hb));
+#pragma unroll
+            for (int k = 0; k < NV; ++k) asm volatile("v_max_i32 %0, 0, %1" : "=v"(y0) : "v"(x0));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = y0;
+    for (int n = 0; n < NACC; ++n) s += acc4[n][0] + acc16[n][0];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) stamps[blockIdx.x] = t1 - t0;
+}
+
 template <class F>
 static int run(const char *name, F kernel, int iters, float *out, unsigned long long *st, int cus) {
     hipEvent_t e0, e1;
@@ -134,6 +170,7 @@ static int run(const char *name, F kernel, int iters, float *out, unsigned long 
     printf("%-28s %.3f ms, %.2f cycles per MFMA, %.1f TFLOP/s\n", name, ms, cyc / mf, mf * 4 * cus * 2.0 * 32 * 32 * 2 / (ms * 1e-3) / 1e12);
     return 0;
 }
+#define SHAPE(K, N, V) run("shape " #K " acc " #N " valu " #V, shape_kernel<K, N, V>, iters, out, st, cus)
 
 int main() {
     int cus = 256;
@@ -157,6 +194,10 @@ int main() {
     run("side 10 s_waitcnt", side_kernel<10>, iters, out, st, cus);
     run("side 11 global_load_dwordx4", side_kernel<11>, iters, out, st, cus);
     run("side 12 ds_write_b32", side_kernel<12>, iters, out, st, cus);
+    run("side 16 global_load_lds_dwordx4", side_kernel<16>, iters, out, st, cus);
+    run("side 17 global_load_dword", side_kernel<17>, iters, out, st, cus);
+    run("side 18 global_load_dwordx4 saddr", side_kernel<18>, iters, out, st, cus);
+    run("side 19 same, every 2nd MFMA", side_kernel<19>, iters, out, st, cus);
     run("side 13 1 max per 8 MFMAs", side_kernel<13>, iters, out, st, cus);
     run("side 14 16 max per 8 MFMAs", side_kernel<14>, iters, out, st, cus);
     run("side 15 32 max per 8 MFMAs", side_kernel<15>, iters, out, st, cus);
@@ -169,5 +210,9 @@ int main() {
     run("switch per 8, 8 max at it", two_kernel<8, 1>, iters, out, st, cus);
     run("switch per 8, 16 max at it", two_kernel<16, 1>, iters, out, st, cus);
     run("switch per 8, 32 max at it", two_kernel<32, 1>, iters, out, st, cus);
+    printf("shapes: 0 = f32 16x16x4, 1 = bf16 16x16x32, 2 = bf16 32x32x16 (TFLOP/s column is for the f32 32x32x2 FLOP count: ignore)\n");
+    SHAPE(0, 1, 0); SHAPE(0, 1, 1); SHAPE(0, 1, 2); SHAPE(0, 4, 0); SHAPE(0, 4, 1); SHAPE(0, 4, 2); SHAPE(0, 4, 4);
+    SHAPE(1, 1, 0); SHAPE(1, 4, 0); SHAPE(1, 4, 1); SHAPE(1, 4, 2); SHAPE(1, 4, 3); SHAPE(1, 4, 4);
+    SHAPE(2, 1, 0); SHAPE(2, 2, 0); SHAPE(2, 2, 1); SHAPE(2, 2, 2); SHAPE(2, 2, 4); SHAPE(2, 2, 8);
     return 0;
 }

@@ -133,9 +133,48 @@ def run():
     print(" ".join(("*" if i in first else "") + "%d" % (np.median(d[:, i, :].sum(axis=1)) - K[i] // 8 * 256 + (np.median(gap[:, i]) if i < 77 else 0)) for i in range(78)))
 
 
+def tiles():
+    """Tile-level stamps (-DF32_STAMP_TILE build): workgroup duration on the shader clock, the clock itself, the share of the launch between workgroups."""
+    import numpy as np
+    import torch
+    lib = ctypes.CDLL(SO)
+    go, raw = setup(lib)
+    for _ in range(3):
+        go()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    go()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    st = np.zeros(4096 * 6, dtype=np.uint64)
+    assert lib.ddnerf_debug_f32_tile_stamps(ctypes.c_void_p(st.ctypes.data)) == 0
+    st = st.reshape(4096, 6).astype(np.int64)
+    st = st[st[:, 2] > 0]                        # (persistent kernel: one row per workgroup = per CU)
+    per_wg = 4096 // len(st)
+    dur = st[:, 2] - st[:, 0]
+    pro = st[:, 1] - st[:, 0]
+    real = (st[:, 4] - st[:, 3]) / 100e6
+    clock = dur / real / 1e6
+    mf = sum(4 * k // 8 for k in K) * 64 * per_wg
+    span = (st[:, 4].max() - st[:, 3].min()) / 100e6 * 1e3
+    print("launch %.4f ms by events; first workgroup start .. last workgroup end %.4f ms on the 100 MHz clock" % (ms, span))
+    print("workgroup: %.0f cycles (median; p10 %.0f, p90 %.0f), of which prologue (features + slice 0 staged) %.0f; MFMAs need %d = %.4f of it" % (
+        np.median(dur), np.percentile(dur, 10), np.percentile(dur, 90), np.median(pro), mf, mf / np.median(dur)))
+    print("in-kernel clock %.0f MHz (median); workgroups per CU x median duration = %.4f ms = %.4f of the launch" % (
+        np.median(clock), 16 // per_wg * np.median(real) * 1e3, 16 // per_wg * np.median(real) * 1e3 / ms))
+    return
+    # consecutive workgroups on one CU: sort by start time, greedy chain by end->start proximity is overkill: report the start-time waves
+    order = np.argsort(st[:, 3])
+    starts = (st[order, 3] - st[:, 3].min()) / 100e6 * 1e6
+    print("start times (us) of workgroups 0, 255, 256, 511, 512, 4095 in start order: %s" % " ".join("%.1f" % starts[i] for i in (0, 255, 256, 511, 512, 4095)))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2:])
+    elif sys.argv[1] == "tiles":
+        tiles()
     elif sys.argv[1] == "time":
         timeit(sys.argv[2:])
     else:
