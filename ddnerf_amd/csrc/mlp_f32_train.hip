@@ -171,6 +171,16 @@ __device__ __forceinline__ unsigned rec_word(float x) {
     const __bf16 lo = (__bf16)(x - (float)hi);
     return ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | __builtin_bit_cast(unsigned short, lo);
 }
+// two at once, 3.5 instructions per element: both hi parts by one v_cvt_pk_bf16_f32, a shift / mask back to fp32, the subtraction, and one
+// v_cvt_pk_bf16_f32 per word (its high half converts hi's fp32 image, exactly, its low half rounds lo) -- the words rec_word gives
+typedef __bf16 rw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rec_word2(float x0, float x1, unsigned &w0, unsigned &w1) {
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((rw_f32x2){x0, x1}, rw_bf16x2));
+    const float hf0 = __builtin_bit_cast(float, h01 << 16), hf1 = __builtin_bit_cast(float, h01 & 0xffff0000u);
+    w0 = __builtin_bit_cast(unsigned, __builtin_convertvector((rw_f32x2){x0 - hf0, hf0}, rw_bf16x2));
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector((rw_f32x2){x1 - hf1, hf1}, rw_bf16x2));
+}
 __device__ __forceinline__ size_t rec_base(int row0, size_t col, int h) { return ((col >> 4) * ACT_ROWS + row0 + 4 * h) * 16 + (col & 15); }
 __device__ __forceinline__ void store_tile_t(float *__restrict__ mat, size_t, int row0, size_t col, int h, const f32x16 &v) {
     unsigned *p = (unsigned *)mat + rec_base(row0, col, h);
@@ -202,58 +212,85 @@ __device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, siz
 __device__ __forceinline__ bool tile_positive(float a) { return a > 0.0f; }
 #endif
 
-template <int DST, int B0, int NBLK>
-__device__ __forceinline__ void load_features(const float *__restrict__ frow, int h, f32x16 (&Breg)[12]) {
-#pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *(const f32x4 *)(frow + 32 * (B0 + b) + 8 * g + 4 * h);
-            Breg[DST + b][4 * g + 0] = v.x;
-            Breg[DST + b][4 * g + 1] = v.y;
-            Breg[DST + b][4 * g + 2] = v.z;
-            Breg[DST + b][4 * g + 3] = v.w;
-        }
-    }
-}
-
 // ---- forward that records activations -----------------------------------------------------------------------
-// One layer: as in mlp_f32.hip, plus: ReLU applied per tile and the tile stored to acts rows [ROW0 + 32 b ...].
-// vmcnt retires in order and counts stores too, so nothing a step waits for may be issued right after the previous
-// tile's 16 stores: every bias tile (the next layer's first one included, `next_bias`) is fetched one step ahead
-// (`bcur` carries it across steps and layers), and the weight fetches wait half a slice after they were issued.
-template <int KIND, int K, int NB, int NEXT_K, int PAR, bool RELU, int NSTORE>
-__device__ __forceinline__ void layer_fwd_train(const float *__restrict__ &wp, const float *__restrict__ bias,
-                                                const float *__restrict__ next_bias, f32x16 &bcur, float *lds,
-                                                const f32x16 (&Breg)[12], f32x16 (&out)[8], float *__restrict__ acts,
-                                                size_t ld, int row0, size_t col, int tid, int lane) {
-    constexpr int N4 = slice_floats(K) / 4;
-    constexpr int NEXT_N4 = NEXT_K > 0 ? slice_floats(NEXT_K) / 4 : 0;
-    const int h = lane >> 5;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const float *cur = lds + ((PAR + b) & 1) * MAX_SLICE_FLOATS;
-        float *nxt = lds + ((PAR + b + 1) & 1) * MAX_SLICE_FLOATS;
-        wp += 4 * N4;
-        f32x16 bnext;
-        auto init = [&](f32x16 &a) {
-            a = bcur;
-            if (b + 1 < NB) bnext = bias_tile(bias + 32 * (b + 1), h);
-            else if (NEXT_K > 0) bnext = bias_tile(next_bias, h);
-        };
-        // (deferring the epilogue of tile b-1 into the MFMA chunks of tile b was measured SLOWER: 5.12 vs 5.04 ms)
-        auto mid = [](int, int) {};
-        auto post = [&](f32x16 &a) {
-            if (b < NSTORE) {
-                if (RELU) a = relu16(a);
-                store_tile_t(acts, ld, row0 + 32 * b, col, h, a);
-            }
-        };
-        if (b + 1 < NB) slice_step_hooks<KIND, K, N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, mid, post);
-        else slice_step_hooks<KIND, K, NEXT_N4>(wp, cur, nxt, Breg, out[b], tid, lane, init, mid, post);
-        if (b + 1 < NB || NEXT_K > 0) bcur = bnext;
+// The inference forward (mlp_f32_fwd.inc: persistent tiles, every output tile takes an LDS round trip behind the next slice's MFMAs)
+// with a recorder: the tile that round trip left in registers -- post-ReLU where the layer has one -- is converted to the record's
+// format in ONE gap between two MFMAs (an fp32 MFMA does not overlap the wave's own vector-ALU instructions: every gap that holds any
+// costs 12 cycles, every instruction 4) and stored by buffer stores, which cost the MFMA chain nothing (scalar tile base + 32-bit lane
+// offset; a store with a 64-bit vector address costs 12 cycles).  Round 3's form (activation, conversion and sixteen 64-bit-address
+// stores behind each slice's last MFMA, 1.2 vector-ALU instructions per MFMA) ran at 0.80 of the inference kernel's rate.
+#include "mlp_f32_fwd.inc"
+
+struct Recorder {
+    static constexpr bool kActive = true;
+    float *acts;
+    size_t ld;
+#ifdef F32_REC
+    __amdgpu_buffer_rsrc_t rs;  // this tile's 8 sample blocks of the record
+    unsigned voff;              // this lane's byte offset inside them
+#if F32_REC == 2
+    static constexpr unsigned kBlockWords = (ACT_ROWS / 2) * 16;
+#else
+    static constexpr unsigned kBlockWords = ACT_ROWS * 16;
+#endif
+    __device__ __forceinline__ void begin_tile(long tile, int wave, int j, int h) {
+        rs = __builtin_amdgcn_make_buffer_rsrc((void *)((unsigned *)acts + (size_t)tile * 8 * kBlockWords), 0, 8 * kBlockWords * 4, 0x00020000);
+#if F32_REC == 2
+        voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * kBlockWords + 2u * h * 16u + (j & 15));
+#else
+        voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * kBlockWords + 4u * h * 16u + (j & 15));
+#endif
     }
-}
+    // registers 4g .. 4g+3 of a tile = its rows 8g .. 8g+3 (+ 4h)
+    __device__ __forceinline__ void store4(int row0, const f32x16 &v, int g) {
+#if F32_REC == 2
+#pragma unroll
+        for (int k = 2 * g; k < 2 * g + 2; ++k) {
+            const rp_f32x2 two = {v[2 * k], v[2 * k + 1]};
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_convertvector(two, rp_bf16x2)), rs, voff,
+                                                  64u * (row0 / 2 + tile_row(2 * k, 0) / 2), 0);
+        }
+#else
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; r += 2) {
+            unsigned w0, w1;
+            rec_word2(v[r], v[r + 1], w0, w1);
+#ifdef F32_EXP_NOSTORE   // (diagnostic builds, tools/f32_clock.py: timing only)
+            asm volatile("" ::"v"(w0), "v"(w1));
+#else
+            __builtin_amdgcn_raw_buffer_store_b32(w0, rs, voff, 64u * (row0 + tile_row(r, 0)), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(w1, rs, voff, 64u * (row0 + tile_row(r + 1, 0)), 0);
+#endif
+        }
+#endif
+    }
+    __device__ __forceinline__ void store(int row0, const f32x16 &v) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store4(row0, v, g);
+    }
+#else
+    // fp32 matrices [feature][sample]: the row's address is scalar arithmetic, this lane's column -- and its lane half's four rows -- a
+    // 32-bit byte offset (global store with a scalar base: nothing for the vector ALU to add)
+    unsigned voff;
+    size_t ld_tile;   // = ld, opaque per tile: the 1280 row addresses are computed where they are used (a few scalar instructions each), not
+                      // hoisted out of the tile loop into 2560 scalar registers
+    float *col0;
+    __device__ __forceinline__ void begin_tile(long tile, int wave, int j, int h) {
+        voff = 4u * (unsigned)(4 * (size_t)h * ld + wave * 32 + j);   // the launcher checks 20 ld < 2^32 bytes
+        ld_tile = ld;
+        asm volatile("" : "+s"(ld_tile));
+        col0 = acts + (size_t)tile * 128;
+    }
+    __device__ __forceinline__ void store4(int row0, const f32x16 &v, int g) {
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; ++r) *(float *)((char *)(col0 + (size_t)(row0 + tile_row(r, 0)) * ld_tile) + voff) = v[r];
+    }
+    __device__ __forceinline__ void store(int row0, const f32x16 &v) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store4(row0, v, g);
+    }
+#endif
+};
 
 struct FwdOffsets {
     int bias_off[NLAYERS];
@@ -264,74 +301,12 @@ __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_fwd_train_kernel)(con
                                                                    const float *__restrict__ packed, FwdOffsets fo,
                                                                    float *__restrict__ raw, float *__restrict__ acts,
                                                                    long M, long ld) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MAX_SLICE_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const long m = (long)blockIdx.x * 128 + wave * 32 + j;  // < ld always (ld is a multiple of 128)
-    const bool valid = m < M;
-    const float *frow = feat + (size_t)(valid ? m : M - 1) * DDNERF_FEAT_LD;
-    f32x16 Breg[12];
-    f32x16 out[8];
-    const float *wp = packed;
-    {
-        constexpr int ROUNDS = slice_floats(96) / 1024;
-        f32x4 pf[ROUNDS];
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) pf[r] = *(const f32x4 *)(wp + 4 * (size_t)(r * 256 + tid));
-        load_features<8, 0, 3>(frow, h, Breg);
-#pragma unroll
-        for (int b = 0; b < 3; ++b) store_tile_t(acts, ld, ROW_X + 32 * b, m, h, Breg[8 + b]);
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) *(f32x4 *)(lds + 4 * (r * 256 + tid)) = pf[r];
-    }
-    __syncthreads();
-    const float *bias = packed;
-    f32x16 bcur = bias_tile(bias + fo.bias_off[0], h);
-    layer_fwd_train<0, 96, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[0], bias + fo.bias_off[1], bcur, lds, Breg, out, acts, ld, 0, m, tid, lane);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
-    for (int l = 1; l <= 3; ++l) {
-        layer_fwd_train<1, 256, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[l], bias + fo.bias_off[l + 1], bcur, lds, Breg, out, acts, ld, 256 * l, m, tid, lane);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) Breg[b] = out[b];
-    }
-    layer_fwd_train<1, 256, 8, 352, 0, true, 8>(wp, bias + fo.bias_off[4], bias + fo.bias_off[5], bcur, lds, Breg, out, acts, ld, 256 * 4, m, tid, lane);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
-    load_features<8, 0, 3>(frow, h, Breg);
-    __builtin_amdgcn_sched_barrier(0);
-    layer_fwd_train<2, 352, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[5], bias + fo.bias_off[6], bcur, lds, Breg, out, acts, ld, 256 * 5, m, tid, lane);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
-    for (int l = 6; l <= 7; ++l) {
-        layer_fwd_train<1, 256, 8, 256, 0, true, 8>(wp, bias + fo.bias_off[l], bias + fo.bias_off[l + 1], bcur, lds, Breg, out, acts, ld, 256 * l, m, tid, lane);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) Breg[b] = out[b];
-    }
-    layer_fwd_train<1, 256, 8, 288, 0, false, 8>(wp, bias + fo.bias_off[8], bias + fo.bias_off[9], bcur, lds, Breg, out, acts, ld, ROW_FEAT, m, tid, lane);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
-    load_features<11, 3, 1>(frow, h, Breg);
-    store_tile_t(acts, ld, ROW_X + 96, m, h, Breg[11]);
-    __builtin_amdgcn_sched_barrier(0);
-    layer_fwd_train<3, 288, 5, 128, 0, true, 4>(wp, bias + fo.bias_off[9], bias + fo.bias_off[10], bcur, lds, Breg, out, acts, ld, ROW_DIR, m, tid, lane);
-    const float alpha = out[4][0];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) Breg[b] = out[b];
-    layer_fwd_train<4, 128, 1, 0, 1, false, 0>(wp, bias + fo.bias_off[10], bias, bcur, lds, Breg, out, acts, ld, 0, m, tid, lane);
-    if (valid) {
-        if (DEPTH) {
-            float *o = raw + (size_t)m * 6;
-            if (h == 0) {
-                *(float2 *)(o) = make_float2(out[0][0], out[0][1]);
-                *(float2 *)(o + 2) = make_float2(out[0][2], alpha);
-            } else {
-                *(float2 *)(o + 4) = make_float2(out[0][0], out[0][1]);
-            }
-        } else if (h == 0) {
-            *(f32x4 *)(raw + (size_t)m * 4) = f32x4{out[0][0], out[0][1], out[0][2], alpha};
-        }
-    }
+    __shared__ __attribute__((aligned(16))) float lds[F32_LDS_FLOATS];
+    Recorder rec;
+    rec.acts = acts;
+    rec.ld = (size_t)ld;
+    // (tiles past M inside ld -- ld is a multiple of 128 -- are recorded too, from the last sample's features: their deltas are zero)
+    mlp_f32_forward_tiles<DEPTH>(lds, feat, packed, 4u * (unsigned)fo.bias_off[0], raw, M, rec);
 }
 
 static FwdOffsets fwd_offsets() {
@@ -350,9 +325,13 @@ DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_forward_train)(const float *feat, const f
     DDN_REQUIRE(feat && packed && raw && acts, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ld >= M && ld % 128 == 0, DDNERF_E_RANGE);
+#ifndef F32_REC
+    DDN_REQUIRE(ld <= (1l << 27), DDNERF_E_RANGE);  // (the fp32 matrices' 32-bit store offsets: 20 ld bytes)
+#endif
     DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16), DDNERF_E_ALIGN);
     FwdOffsets fo = fwd_offsets();
-    dim3 grid((unsigned)((M + 127) / 128));
+    const long ntiles = (M + 127) / 128, cus = ddn_cu_count();
+    dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));   // persistent (mlp_f32_fwd.inc)
     if (depth_head)
         hipLaunchKernelGGL(F32_NAME(mlp_f32_fwd_train_kernel)<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
                            acts, M, ld);

@@ -5,6 +5,7 @@
 //     4 two reads + two max   5 v_accvgpr_read + v_max_i32 + v_accvgpr_write back   6 one ds_read_b128   7 MFMA B operand from an AGPR
 //     8 s_mov_b32   9 s_nop 0   10 s_waitcnt lgkmcnt(0)   11 buffer-less global_load_dwordx4   12 ds_write_b32
 //     16 global_load_lds_dwordx4 (LDS-DMA)   17 global_load_dword   18 global_load_dwordx4 with scalar base   19 the same behind every 2nd MFMA
+//     20 global_store_dword with scalar base   21 with a 64-bit vector address   22 scalar base, behind every 4th MFMA
 //     13 one v_max_i32 behind every 8th MFMA only   14 sixteen v_max_i32 behind every 8th MFMA   15 thirty-two behind every 8th
 //  two<MODE>:   two INDEPENDENT chains (a[0:15], a[16:31]) alternating; MODE 0 nothing, 2 one v_max_i32 behind each MFMA, 4 four
 //  swtch<N>:    chains of 8 MFMAs on alternating accumulators (a slice boundary every 8 MFMAs), N v_max_i32 AT the boundary
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256, 1) void side_kernel(float *out, int iters, uns
     float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f + threadIdx.x * 1e-4f;
     float x0 = a, x1 = b, y0 = 0, y1 = 0;
     float4 dsv = {0, 0, 0, 0};
-    const unsigned laddr = (threadIdx.x & 63) * 16;
+    const unsigned laddr = (threadIdx.x & 63) * 16 % 1024;
     // a[0:15] = the chain's accumulator, a[16:31] = another tile (the side work's operand), a32 = B operand of mode 7
     asm volatile("v_accvgpr_write_b32 a32, %0" ::"v"(b));
 #define INIT(n) asm volatile("v_accvgpr_write_b32 a" #n ", %0" ::"v"(0.0f));
@@ -67,6 +68,9 @@ __global__ __launch_bounds__(256, 1) void side_kernel(float *out, int iters, uns
             if (MODE == 17) asm volatile("global_load_dword %0, %1, off" : "=v"(dsv.x) : "v"(out + (threadIdx.x & 63)));
             if (MODE == 18) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dsv) : "v"(laddr), "s"(out));
             if (MODE == 19 && s % 2 == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dsv) : "v"(laddr), "s"(out));
+            if (MODE == 20) asm volatile("global_store_dword %0, %1, %2" ::"v"(laddr), "v"(x0), "s"(out + 256 * blockIdx.x) : "memory");
+            if (MODE == 21) asm volatile("global_store_dword %0, %1, off" ::"v"(out + 64 * blockIdx.x + (threadIdx.x & 63)), "v"(x0) : "memory");
+            if (MODE == 22 && s % 4 == 0) asm volatile("global_store_dword %0, %1, %2" ::"v"(laddr), "v"(x0), "s"(out + 256 * blockIdx.x) : "memory");
             if (MODE == 12) asm volatile("ds_write_b32 %0, %1" ::"v"(laddr), "v"(x0));
             if (MODE == 13 && s % 8 == 7) asm volatile("v_max_i32 %0, 0, %1" : "=v"(y0) : "v"(x0));
             if ((MODE == 14 || MODE == 15) && s % 8 == 7) {
@@ -194,6 +198,9 @@ int main() {
     run("side 10 s_waitcnt", side_kernel<10>, iters, out, st, cus);
     run("side 11 global_load_dwordx4", side_kernel<11>, iters, out, st, cus);
     run("side 12 ds_write_b32", side_kernel<12>, iters, out, st, cus);
+    run("side 20 global_store_dword saddr", side_kernel<20>, iters, out, st, cus);
+    run("side 21 global_store_dword 64-bit", side_kernel<21>, iters, out, st, cus);
+    run("side 22 store saddr every 4th", side_kernel<22>, iters, out, st, cus);
     run("side 16 global_load_lds_dwordx4", side_kernel<16>, iters, out, st, cus);
     run("side 17 global_load_dword", side_kernel<17>, iters, out, st, cus);
     run("side 18 global_load_dwordx4 saddr", side_kernel<18>, iters, out, st, cus);

@@ -20,7 +20,7 @@ K = [96] * 8 + [256] * 32 + [352] * 8 + [256] * 24 + [288] * 5 + [128]
 def build(defs):
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-function"]
-                          + defs + ["-shared", os.path.join(CSRC, "mlp_f32.hip"), "-o", SO])
+                          + defs + ["-shared", os.path.join(CSRC, "mlp_f32.hip"), os.path.join(CSRC, "mlp_f32_train_rec.hip"), "-o", SO])
     print(SO)
 
 
@@ -39,6 +39,46 @@ def setup(lib):
     P = ctypes.c_void_p
     assert lib.ddnerf_mlp_f32_pack(P(params.data_ptr()), 1, P(packed.data_ptr()), None) == 0
     return lambda: lib.ddnerf_mlp_f32_forward(P(feat.data_ptr()), P(packed.data_ptr()), 1, P(raw.data_ptr()), ctypes.c_long(M), None), raw
+
+
+def time_train(names):
+    """Interleaved launch times of the record-writing training forward (ddnerf_mlp_f32_forward_train_rec) of several builds."""
+    import torch
+    M = 524288
+    res = {}
+    libs = {}
+    for nm in names:
+        path = os.path.join(CSRC, "libddnerf_hip.so") if nm == "product" else os.path.join(ROOT, "tools", "lib", "f32_%s.so" % nm)
+        lib = ctypes.CDLL(path)
+        go, raw = setup(lib)
+        libs[nm] = lib
+    P = ctypes.c_void_p
+    torch.manual_seed(0)
+    feat = torch.randn(M, 128, device="cuda")
+    nout = [256] * 9 + [1, 128, 3, 2]
+    nin = [96, 256, 256, 256, 256, 352, 256, 256, 256, 256, 283, 128, 128]
+    params = torch.randn(sum(o * i + o for o, i in zip(nout, nin)), device="cuda") * 0.05
+    acts = torch.empty(2560, M, device="cuda")
+    raw = torch.empty(M, 6, device="cuda")
+    for rep in range(4):
+        for nm, lib in libs.items():
+            n = lib.ddnerf_mlp_f32_packed_floats
+            n.restype = ctypes.c_size_t
+            packed = torch.empty(n(1), device="cuda")
+            assert lib.ddnerf_mlp_f32_pack(P(params.data_ptr()), 1, P(packed.data_ptr()), None) == 0
+            go = lambda: lib.ddnerf_mlp_f32_forward_train_rec(P(feat.data_ptr()), P(packed.data_ptr()), 1, P(raw.data_ptr()), P(acts.data_ptr()),
+                                                             ctypes.c_long(M), ctypes.c_long(M), None)
+            for _ in range(3):
+                assert go() == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                go()
+            e1.record()
+            torch.cuda.synchronize()
+            res.setdefault(nm, []).append(e0.elapsed_time(e1) / 10)
+    for nm in names:
+        print("%-12s forward_train_rec %.4f ms per launch (median of 4 x 10)  [%s]" % (nm, sorted(res[nm])[2], " ".join("%.4f" % v for v in res[nm])))
 
 
 def timeit(names):
@@ -175,6 +215,8 @@ if __name__ == "__main__":
         build(sys.argv[2:])
     elif sys.argv[1] == "tiles":
         tiles()
+    elif sys.argv[1] == "time_train":
+        time_train(sys.argv[2:])
     elif sys.argv[1] == "time":
         timeit(sys.argv[2:])
     else:
