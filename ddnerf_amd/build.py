@@ -127,14 +127,18 @@ def generate(force: bool = False, verbose: bool = False) -> None:
 
 def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
     generate(force, verbose)
-    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc", ".py"))]
+    # (sources include sources -- mlp_f32_train_rec.hip is mlp_f32_train.hip under a macro, mlp_f16.hip is mlp_bf16.hip --: every
+    # translation unit depends on every file that can be included)
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc", ".py")) or (h.endswith(".hip") and h not in SOURCES)]
+    includes = {"mlp_f16.hip": ["mlp_bf16.hip"], "mlp_f16_g2.hip": ["mlp_bf16_g2.hip"],
+                "mlp_f32_train_rec.hip": ["mlp_f32_train.hip"], "mlp_f32_train_recp.hip": ["mlp_f32_train.hip"]}
     hdrs += [os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
     objs, todo = [], []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         o = s[:-4] + ".o"
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, [s] + hdrs + [os.path.join(CSRC, i) for i in includes.get(src, [])]):
             todo.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -344,6 +344,7 @@ DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_forward_train)(const float *feat, const f
 // ---- fused backward-data ------------------------------------------------------------------------------------
 // One backward step: NB tiles of the outgoing delta.  MASK: multiply by relu'(recorded activation), whose tile is
 // requested at the start of its slice and used a whole slice later.
+// (step d0 only -- K = 32: four MFMA chunks per slice, too short for the schedule below)
 template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK>
 __device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *lds, const f32x16 (&Breg)[12],
                                          f32x16 (&out)[8], const float *__restrict__ acts, float *__restrict__ deltas,
@@ -375,16 +376,111 @@ __device__ __forceinline__ void step_bwd(const float *__restrict__ &wp, float *l
     }
 }
 
+// The recorded activations of one tile, for the ReLU masks: the record words of rows row0 + tile_row(r, h), as load_tile_t gives them
+// (tile_positive() reads them), by buffer loads where the record's blocked layout allows a 32-bit offset.
+struct ActLoader {
+    const float *acts;
+    size_t ld;
+#ifdef F32_REC
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff;
+    __device__ __forceinline__ void begin_tile(long tile, int wave, int j, int h) {
+        rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const unsigned *)acts + (size_t)tile * 8 * Recorder::kBlockWords), 0, 8 * Recorder::kBlockWords * 4, 0x00020000);
+#if F32_REC == 2
+        voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * Recorder::kBlockWords + 2u * h * 16u + (j & 15));
+#else
+        voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * Recorder::kBlockWords + 4u * h * 16u + (j & 15));
+#endif
+    }
+    __device__ __forceinline__ f32x16 load(int row0) const {
+        f32x16 v;
+#if F32_REC == 2
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 64u * (row0 / 2 + tile_row(2 * k, 0) / 2), 0);
+            v[2 * k] = __builtin_bit_cast(float, w & 0xffffu);
+            v[2 * k + 1] = __builtin_bit_cast(float, w >> 16);
+        }
+#else
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 64u * (row0 + tile_row(r, 0)), 0));
+#endif
+        return v;
+    }
+#else
+    size_t col;
+    int h;
+    __device__ __forceinline__ void begin_tile(long tile, int wave, int j, int h_) {
+        col = (size_t)tile * 128 + wave * 32 + j;
+        h = h_;
+    }
+    __device__ __forceinline__ f32x16 load(int row0) const { return load_tile_t(acts, ld, row0, col, h); }
+#endif
+};
+
+// Steps d1 .. d9 on the forward's slice step (mlp_f32_fwd.inc): the tile of slice b - 1 goes through the wave's LDS scratch behind the
+// MFMAs of slice b -- pushed and pulled back into vector registers by LDS instructions (free beside MFMAs; an accumulator-file register
+// cannot be a vector-ALU source) -- and is masked (a compare and a select per element), converted and recorded behind the slice's
+// last weight fetch.  The accumulators start from the MFMA's zero operand, not from sixteen moves.  The step's last tile makes the trip
+// behind the next step's slice 0 (PEND: 1 masked by `act_pend`, the activation tile this step fetched for it; 2 unmasked).
+template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK, int PEND>
+__device__ __forceinline__ void step_bwd_early(__amdgpu_buffer_rsrc_t wsrc, unsigned &woff, float *lds, float *scr_wave, f32x16 (&Breg)[12],
+                                               f32x16 (&out)[8], f32x4 (&carry)[2], f32x16 &act_pend, const ActLoader &al, Recorder &rec,
+                                               int row0, int pend_row0, int tid, int lane) {
+    static_assert(!PEND || bsel<KIND>(9) != 7, "PEND: tile 7 must not feed the first ten chunks");
+    static_assert(K / 8 >= 12, "the round-trip schedule uses chunks 0..10");
+    constexpr int ROUNDS = slice_floats(K) / 1024, NEXT_ROUNDS = NEXT_K > 0 ? slice_floats(NEXT_K) / 1024 : 0, NQ = K / 8;
+    float *scr = scr_wave + lane;
+    f32x16 act_prev = act_pend;   // the activation tile of the tile in flight through the scratch (slice 0: the step before's last)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float *cur = lds + ((PAR + b) & 1) * MAX_SLICE_FLOATS;
+        float *nxt = lds + ((PAR + b + 1) & 1) * MAX_SLICE_FLOATS;
+        woff += 4096u * ROUNDS;
+        f32x16 act_this, bunused;
+        auto init = [&](f32x16 &a) {
+            a = f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (MASK) act_this = al.load(row0 + 32 * b);
+        };
+        auto mid = [&](int q, int i) {
+            const bool mine = b >= 1, pend = PEND != 0 && b == 0;
+            if (!mine && !pend) return;
+            f32x16 &t = mine ? out[b >= 1 ? b - 1 : 0] : Breg[7];
+            const bool masked = mine ? MASK : PEND == 1;
+            if (q >= 1 && q <= 4) plain_push(scr, t[4 * (q - 1) + i], 4 * (q - 1) + i);
+            if (q >= 5 && q <= 8) t[4 * (q - 5) + i] = relu_pull(scr, 4 * (q - 5) + i);
+            if (i == 0) {
+                const int R = b + 1 < NB ? ROUNDS : NEXT_ROUNDS;
+                const int after = R > 0 ? ((R - 1) * NQ) / (2 * R) + 1 : 7, q0 = after > 7 ? after : 7;
+                if (q >= q0 && q < q0 + 4) {   // mask (compare + select) and record four elements in one gap
+                    if (masked) {
+#pragma unroll
+                        for (int r = 4 * (q - q0); r < 4 * (q - q0) + 4; ++r) t[r] = tile_positive(act_prev[r]) ? t[r] : 0.0f;
+                    }
+                    rec.store4(mine ? row0 + 32 * (b - 1) : pend_row0, t, q - q0);
+                }
+            }
+        };
+        if (b + 1 < NB) slice_step_early<KIND, K, ROUNDS, K>(wsrc, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
+        else slice_step_early<KIND, K, NEXT_ROUNDS, NEXT_K>(wsrc, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
+        if (MASK) act_prev = act_this;
+    }
+    if (MASK) act_pend = act_prev;
+}
+
 template <bool DEPTH>
 __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_bwd_data_kernel)(const float *__restrict__ g_raw,
-                                                                  const float *__restrict__ packed_t,
+                                                                  const float *__restrict__ packed_t, unsigned packed_bytes,
                                                                   const float *__restrict__ acts,
                                                                   float *__restrict__ deltas, long M, long ld) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * MAX_SLICE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[F32_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const long m = (long)blockIdx.x * 128 + wave * 32 + j;
     const bool valid = m < M;
+    float *scr_wave = lds + 2 * MAX_SLICE_FLOATS + SCR_FLOATS * wave;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) relu_rezero(scr_wave, lane, k);
     f32x16 Breg[12];
     f32x16 out[8];
     const float *wp = packed_t;
@@ -417,17 +513,49 @@ __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_bwd_data_kernel)(cons
     step_bwd<10, 32, 4, 160, 0, true>(wp, lds, Breg, out, acts, deltas, ld, ROW_DIR, m, tid, lane);
 #pragma unroll
     for (int b = 0; b < 4; ++b) Breg[b] = out[b];
+    // from here on: the forward's slice step (barrier in front of a slice's last chunk, first fragments handed over)
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)packed_t, 0, packed_bytes, 0x00020000);
+    unsigned woff = 4u * (unsigned)(wp - packed_t);
+    f32x4 carry[2];
+    carry[0] = *(const f32x4 *)(lds + j * (160 + 4) + 4 * h);
+    carry[1] = *(const f32x4 *)(lds + j * (160 + 4) + 4 * h + 8);
+    ActLoader al;
+    al.acts = acts;
+    al.ld = (size_t)ld;
+    al.begin_tile(blockIdx.x, wave, j, h);
+    Recorder rec;
+    rec.acts = deltas;
+    rec.ld = (size_t)ld;
+    rec.begin_tile(blockIdx.x, wave, j, h);
+    f32x16 act_pend = {};
+#define NEXT_STEP() _Pragma("unroll") for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     // d1: d(feat) = W_dir[:, :256]^T d(dir hidden) + W_alpha^T d(raw)[3]; fc_feat has no activation
-    step_bwd<11, 160, 8, 256, 0, false>(wp, lds, Breg, out, acts, deltas, ld, ROW_FEAT, m, tid, lane);
+    step_bwd_early<11, 160, 8, 256, 0, false, 0>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, ROW_FEAT, 0, tid, lane);
+    NEXT_STEP();
+    // d2..d9: d(h_l) = W_{l+1}^T d(h_{l+1}) * relu'(h_l),  l = 7..0 (straight-line: one step's tiles ARE the next one's B operands)
+    step_bwd_early<1, 256, 8, 256, 0, true, 2>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 7, ROW_FEAT + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 6, 256 * 7 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 5, 256 * 6 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 4, 256 * 5 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 3, 256 * 4 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 2, 256 * 3 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 1, 256 * 2 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_early<1, 256, 8, 0, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 0, 256 * 1 + 224, tid, lane);
+#undef NEXT_STEP
+    // the last tile of the last step: nothing left to hide it behind
+    {
+        f32x16 a = out[7];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) Breg[b] = out[b];
-    // d2..d9: d(h_l) = W_{l+1}^T d(h_{l+1}) * relu'(h_l),  l = 7..0
-    for (int l = 7; l >= 1; --l) {
-        step_bwd<1, 256, 8, 256, 0, true>(wp, lds, Breg, out, acts, deltas, ld, 256 * l, m, tid, lane);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+        for (int r = 0; r < 16; ++r) a[r] = tile_positive(act_pend[r]) ? a[r] : 0.0f;
+        rec.store(224, a);
     }
-    step_bwd<1, 256, 8, 0, 0, true>(wp, lds, Breg, out, acts, deltas, ld, 0, m, tid, lane);
 }
 
 DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_backward_data)(const float *g_raw, const float *packed_t, const float *acts,
@@ -436,12 +564,13 @@ DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_backward_data)(const float *g_raw, const 
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ld >= M && ld % 128 == 0, DDNERF_E_RANGE);
     DDN_REQUIRE(ddn_aligned(packed_t, 16), DDNERF_E_ALIGN);
+    const unsigned packed_bytes = 4u * (unsigned)make_plan_t(depth_head).total;
     dim3 grid((unsigned)((M + 127) / 128));
     if (depth_head)
-        hipLaunchKernelGGL(F32_NAME(mlp_f32_bwd_data_kernel)<true>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, acts,
+        hipLaunchKernelGGL(F32_NAME(mlp_f32_bwd_data_kernel)<true>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, packed_bytes, acts,
                            deltas, M, ld);
     else
-        hipLaunchKernelGGL(F32_NAME(mlp_f32_bwd_data_kernel)<false>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, acts,
+        hipLaunchKernelGGL(F32_NAME(mlp_f32_bwd_data_kernel)<false>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, packed_bytes, acts,
                            deltas, M, ld);
     return ddn_launch_status();
 }
