@@ -234,6 +234,9 @@ struct Recorder {
     static constexpr unsigned kBlockWords = ACT_ROWS * 16;
 #endif
     __device__ __forceinline__ void begin_tile(long tile, int wave, int j, int h) {
+#ifdef F32_EXP_SMALLSTORE   // (diagnostic builds: the workgroups of an XCD share the records of two tiles: the stores stay in its L2)
+        tile = blockIdx.x & 15;   // (2 tiles = 2.6 MB per XCD)
+#endif
         rs = __builtin_amdgcn_make_buffer_rsrc((void *)((unsigned *)acts + (size_t)tile * 8 * kBlockWords), 0, 8 * kBlockWords * 4, 0x00020000);
 #if F32_REC == 2
         voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * kBlockWords + 2u * h * 16u + (j & 15));

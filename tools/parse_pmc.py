@@ -33,7 +33,7 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
     # factor measured on the same pattern in the same call.
     fetch_true_kb = fk["FETCH_SIZE_raw_KB"] / BF16_FACTOR if mlp in ("bf16", "fp16") else 2 * fk["FETCH_SIZE_raw_KB"]
     traffic = (fetch_true_kb + fk["WRITE_SIZE_KB"]) * 1024
-    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"], "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"], "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
             "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}[mlp]
     digest = hashlib.md5()
     for f_ in srcs:
@@ -56,7 +56,7 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
                                      "fetched 50 us earlier, served by the L2 / MALL when they are still there and counted here when not; plus the packed weight "
                                      "image (1.4 MB per XCD) and write granularity.  At the measured launch time the total is < 15 % of HBM bandwidth" if mlp in ("bf16", "fp16") else
                                      "by design the fp32 / x3 kernels re-read the 96 xyz feature columns for the skip layer instead of holding 48 registers "
-                                     "across four layers (+201 MB if it misses L2), and 4096 workgroups each stream the whole weight image (2.6 MB) through L2; "
+                                     "across four layers (+201 MB if it misses L2), and every 128-sample tile streams the whole weight image (2.6 MB) through L2; "
                                      "at the measured launch time this is < 2 % (fp32) / < 6 % (x3) of HBM bandwidth"),
            "kernels": table}
     json.dump(out, open(os.path.join(R, "profiles", ROUND + "_hbm_traffic_%s.json" % mlp), "w"), indent=1)
