@@ -85,6 +85,39 @@ def test_mlp_f32_ragged_and_large(ops):
         assert maxerr(raw, ref) <= 2e-6 * max(1.0, np.abs(ref).max()), (M, depth)
 
 
+def test_mlp_f32_persistent_tiles(ops):
+    """The fp32 forward is persistent (one workgroup per CU walks the 128-sample tiles, handing the next tile's first weight slice,
+    fragments, bias tile and features over in registers / LDS): more tiles than workgroups with a ragged last tile, against the oracle
+    on rows of the first tile, of a second-trip tile and of the ragged tail, and row-for-row against launches of those tiles alone;
+    the training forward (same body with a recorder) writes the records of the same activations at that size."""
+    rng = np.random.default_rng(15)
+    M, depth = 128 * (2 * 256 + 3) + 77, True     # 515 full tiles + 77 samples: workgroups take 2 or 3 tiles
+    feat = np.zeros((M, 128), np.float32)
+    feat[:, :123] = rng.uniform(-1, 1, (M, 123)).astype(np.float32)
+    sd = synthetic.make_state_dict(depth, 3, 4.0)
+    flat = dev(flat_params(sd, depth))
+    packed = ops.mlp_f32_pack(flat, depth)
+    fd = dev(feat)
+    raw = ops.mlp_f32_forward(fd, packed, depth)
+    for lo, hi in ((0, 128), (128 * 256, 128 * 257 + 5), (128 * 513, 128 * 514), (M - 77 - 128, M)):
+        ref = O.mlp_forward(feat[lo:hi], sd, depth)
+        assert maxerr(host(raw[lo:hi]), ref) <= 2e-6 * max(1.0, np.abs(ref).max()), (lo, hi)
+        alone = ops.mlp_f32_forward(fd[lo:hi].contiguous(), packed, depth)     # the same rows as the first tiles of their workgroups
+        assert torch.equal(alone, raw[lo:hi]), (lo, hi)
+    raw_t, acts = ops.mlp_f32_forward_train(fd, packed, depth)
+    raw_r, rec = ops.mlp_f32_forward_train(fd, packed, depth, rec=True)
+    assert torch.equal(raw_t, raw) and torch.equal(raw_r, raw)
+    ld = acts.shape[1]
+    assert torch.equal(rec.view(torch.int32)[:, :ld].reshape(-1, 2560, 16)[: M // 16, :2555], ops.x3_split(acts).view(torch.int32).reshape(-1, 2560, 16)[: M // 16, :2555])
+    cols = torch.tensor([0, 127, 128 * 256 + 3, 128 * 514 + 100, M - 1], device="cuda")
+    a = host(acts[:, cols])                         # [2560, 5]: layer outputs (post-ReLU), fc_feat, dir hidden, input columns
+    for k, c in enumerate(cols.tolist()):
+        x = feat[c]
+        assert np.array_equal(a[2432:2555, k], x[:123]), c
+        h0 = np.maximum(sd["layers_xyz.0.weight"].astype(np.float64) @ x[:96].astype(np.float64) + sd["layers_xyz.0.bias"], 0.0)
+        assert np.abs(a[0:256, k] - h0).max() <= 1e-5 * max(1.0, np.abs(h0).max()), c
+
+
 def test_dd_records_match_boolean_indexing(ops):
     """ops.dd_records (three small kernels) against the reference's expression pdf = w / w.sum(-1); x[pdf > 0.1] evaluated by
     torch on the CPU (ATen's summation order), incl. an all-zero row (NaN pdf: nothing selected) and ragged widths"""
