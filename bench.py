@@ -48,7 +48,7 @@ CONFIGS = {
     "config_ff_mipnerf.yml": ("llff", "fp32", 4096),
     "config_360_mipnerf.yml": ("real360", "fp32", 8192),
 }
-KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"],
                   "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
                   "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
 
