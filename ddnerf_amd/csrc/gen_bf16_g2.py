@@ -53,6 +53,7 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 #   touch=<file>      code-page touch: every block starts with an s_load_dword from the code address listed for it in <file> (one signed
 #                     byte offset from the s_getpc at the body's top per block; `nop` = a filler of the same size) -- see tools/g2_touch.py
 #   nodma=1 / nox=1   TIMING ONLY, results wrong: no LDS-DMA pieces / no feature fetches are issued
+#   kmax=n            the re-pack of the previous block may use the gaps of the first n k-steps of an 8-k-step block (product: 7)
 #   nobarrier=1       TIMING ONLY, results wrong (races): the period barriers are not issued -- what do the 82 barriers of a tile cost?
 #   pf=1              the L2 prefetch touches of feature rows of rounds 3's body are issued again (a load of one word of each row of a group into
 #                     a register nothing reads, one or two passes ahead of the group's feature fetch; results unchanged).  Round 4
@@ -63,13 +64,13 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 #   touchglc=1        the code-page touches bypass the scalar cache (glc)
 #   xpolicy=a_b       cache-policy bits of the feature fetches instead of `nt` (underscores for spaces; `none` = default policy)
 EXP_DEFAULT = dict(stamp_periods="0", stamp_ksteps="", sgpr_stamps="", dummy_valu="0,0", skip_fill="", skip_every="1", head_pad="0", align="0",
-                   dma_span="1/1", touch="", nodma="0", nox="0", pf="0", xpolicy="nt", pfpolicy="none", xsame="0", touchglc="0", nobarrier="0")
+                   dma_span="1/1", touch="", nodma="0", nox="0", pf="0", xpolicy="nt", pfpolicy="none", xsame="0", touchglc="0", nobarrier="0", kmax="7")
 EXP = dict(EXP_DEFAULT)
 
 
 def set_experiment(opts):
     """install experiment switches (dict key -> string); unknown keys are an error"""
-    global STAMP_PERIODS, DUMMY_VALU, SKIP_FILL, SKIP_EVERY, HEAD_PAD, ALIGN, STAMP_KSTEPS, DMA_SPAN_NUM, DMA_SPAN_DEN, SGPR_STAMPS, TOUCH, NODMA, NOX, NOPF, XPOLICY, PFPOLICY, XSAME, TOUCHGLC, NOBARRIER
+    global STAMP_PERIODS, DUMMY_VALU, SKIP_FILL, SKIP_EVERY, HEAD_PAD, ALIGN, STAMP_KSTEPS, DMA_SPAN_NUM, DMA_SPAN_DEN, SGPR_STAMPS, TOUCH, NODMA, NOX, NOPF, XPOLICY, PFPOLICY, XSAME, TOUCHGLC, NOBARRIER, KMAX
     for k in opts:
         if k not in EXP_DEFAULT:
             raise SystemExit("gen_bf16_g2: unknown experiment switch %r (known: %s)" % (k, ", ".join(sorted(EXP_DEFAULT))))
@@ -93,6 +94,7 @@ def set_experiment(opts):
     PFPOLICY = "" if EXP["pfpolicy"] == "none" else " " + EXP["pfpolicy"].replace("_", " ")
     XSAME, TOUCHGLC = EXP["xsame"] == "1", EXP["touchglc"] == "1"
     NOBARRIER = EXP["nobarrier"] == "1"
+    KMAX = int(EXP["kmax"])
 
 
 def options_string():
@@ -587,7 +589,7 @@ class Gen:
         for i, blk in enumerate(blocks):
             l, b, g, par, K0, order = blk["l"], blk["b"], blk["g"], blk["par"], blk["K0"], blk["order"]
             nks = len(order)
-            kmax = nks if nks <= 4 else min(nks - 1, 7)
+            kmax = nks if nks <= 4 else min(nks - 1 if KMAX == 7 else nks, KMAX)
             self.comment("---- block %d: layer %d block %d group %d (period %d)" % (i, l, b, g, blk["period"]))
             if TOUCH is not None:       # (experiment: 8 bytes per block either way, so that a second pass over the addresses changes no address)
                 if TOUCH[i] == "nop":

@@ -26,26 +26,8 @@ __device__ __forceinline__ constexpr int bsel(int q) {
                      : q / 4;
 }
 
-__device__ __forceinline__ f32x16 bias_tile(const float *__restrict__ bias32, int h) {
-    f32x16 v;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *(const f32x4 *)(bias32 + 8 * g + 4 * h);
-        v[4 * g + 0] = b.x;
-        v[4 * g + 1] = b.y;
-        v[4 * g + 2] = b.z;
-        v[4 * g + 3] = b.w;
-    }
-    return v;
-}
-
-__device__ __forceinline__ f32x16 relu16(f32x16 v) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
-    return v;
-}
-
-// One slice step: fetch the NEXT slice (PF_N4 float4 pieces, 0 = nothing to fetch) into registers, multiply the
+// One slice step in its round-1 form (round 4: only step d0 of the backward pass, whose K = 32 slices are four MFMA chunks long, still
+// runs it; everything else is on slice_step_early, mlp_f32_fwd.inc): fetch the NEXT slice (PF_N4 float4 pieces, 0 = nothing to fetch) into registers, multiply the
 // current one out of LDS, then park the fetched slice in the other LDS buffer; one barrier.
 //   init(acc)  -- accumulator start value (bias tile / zero) and any loads whose latency should hide under the MFMAs
 //   mid(q, NQ) -- runs inside MFMA chunk q of NQ (work to spread behind the MFMAs: stores of the previous tile)
@@ -86,15 +68,6 @@ __device__ __forceinline__ void slice_step_hooks(const float *__restrict__ next_
     }
     post(acc);
     __syncthreads();
-}
-
-template <int KIND, int K, int PF_N4>
-__device__ __forceinline__ void slice_step(const float *__restrict__ next_src, const float *__restrict__ bias32,
-                                           const float *cur, float *nxt, const f32x16 (&Breg)[12], f32x16 &acc,
-                                           int tid, int lane) {
-    slice_step_hooks<KIND, K, PF_N4>(
-        next_src, cur, nxt, Breg, acc, tid, lane, [&](f32x16 &a) { a = bias_tile(bias32, lane >> 5); }, [](int, int) {},
-        [](f32x16 &) {});
 }
 
 // row of accumulator register r inside a 32-row tile, for lane half h

@@ -395,6 +395,20 @@ struct ActLoader {
         voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * Recorder::kBlockWords + 4u * h * 16u + (j & 15));
 #endif
     }
+    // registers 4g .. 4g+3 of the tile's record words
+    __device__ __forceinline__ void load4(f32x16 &v, int row0, int g) const {
+#if F32_REC == 2
+#pragma unroll
+        for (int k = 2 * g; k < 2 * g + 2; ++k) {
+            const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 64u * (row0 / 2 + tile_row(2 * k, 0) / 2), 0);
+            v[2 * k] = __builtin_bit_cast(float, w & 0xffffu);
+            v[2 * k + 1] = __builtin_bit_cast(float, w >> 16);
+        }
+#else
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; ++r) v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 64u * (row0 + tile_row(r, 0)), 0));
+#endif
+    }
     __device__ __forceinline__ f32x16 load(int row0) const {
         f32x16 v;
 #if F32_REC == 2
@@ -418,6 +432,10 @@ struct ActLoader {
         h = h_;
     }
     __device__ __forceinline__ f32x16 load(int row0) const { return load_tile_t(acts, ld, row0, col, h); }
+    __device__ __forceinline__ void load4(f32x16 &v, int row0, int g) const {
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; ++r) v[r] = TLOAD(&acts[TADDR(row0 + tile_row(r, h), ld, col)]);
+    }
 #endif
 };
 
@@ -426,49 +444,59 @@ struct ActLoader {
 // cannot be a vector-ALU source) -- and is masked (a compare and a select per element), converted and recorded behind the slice's
 // last weight fetch.  The accumulators start from the MFMA's zero operand, not from sixteen moves.  The step's last tile makes the trip
 // behind the next step's slice 0 (PEND: 1 masked by `act_pend`, the activation tile this step fetched for it; 2 unmasked).
-template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK, int PEND>
+// The recorded activations (the masks) come from HBM, and vmcnt retires loads in order: a record fetch issued in FRONT of a slice's
+// weight fetches must have arrived before the first of those may be parked, half a slice (1.8 us) later.  They are issued BEHIND the
+// slice's last weight fetch and its record stores instead, two slices ahead of their use (tile b + 1 during slice b, used behind
+// slice b + 2; the next step's tile 0 during this step's last slice: NEXT_MASK, next_row0): three activation tiles in flight.
+template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK, int PEND, bool NEXT_MASK>
 __device__ __forceinline__ void step_bwd_early(__amdgpu_buffer_rsrc_t wsrc, unsigned &woff, float *lds, float *scr_wave, f32x16 (&Breg)[12],
-                                               f32x16 (&out)[8], f32x4 (&carry)[2], f32x16 &act_pend, const ActLoader &al, Recorder &rec,
-                                               int row0, int pend_row0, int tid, int lane) {
+                                               f32x16 (&out)[8], f32x4 (&carry)[2], f32x16 &act_pend, f32x16 &act_first, const ActLoader &al,
+                                               Recorder &rec, int row0, int pend_row0, int next_row0, int tid, int lane) {
     static_assert(!PEND || bsel<KIND>(9) != 7, "PEND: tile 7 must not feed the first ten chunks");
-    static_assert(K / 8 >= 12, "the round-trip schedule uses chunks 0..10");
+    static_assert(K / 8 >= 20, "the round-trip schedule uses chunks 1 .. q0 + 7");
     constexpr int ROUNDS = slice_floats(K) / 1024, NEXT_ROUNDS = NEXT_K > 0 ? slice_floats(NEXT_K) / 1024 : 0, NQ = K / 8;
     float *scr = scr_wave + lane;
-    f32x16 act_prev = act_pend;   // the activation tile of the tile in flight through the scratch (slice 0: the step before's last)
+    f32x16 act_prev = act_pend;    // the activation tile of the tile in flight through the scratch (slice 0: the step before's last)
+    f32x16 act_hold = act_first;   // ... of the tile this slice computes
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const float *cur = lds + ((PAR + b) & 1) * MAX_SLICE_FLOATS;
         float *nxt = lds + ((PAR + b + 1) & 1) * MAX_SLICE_FLOATS;
         woff += 4096u * ROUNDS;
-        f32x16 act_this, bunused;
-        auto init = [&](f32x16 &a) {
-            a = f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            if (MASK) act_this = al.load(row0 + 32 * b);
-        };
+        f32x16 act_load = act_hold, bunused;   // ... of the tile the NEXT slice computes, fetched during this one
+        auto init = [&](f32x16 &a) { a = f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; };
         auto mid = [&](int q, int i) {
+            const int R = b + 1 < NB ? ROUNDS : NEXT_ROUNDS;
+            const int after = R > 0 ? ((R - 1) * NQ) / (2 * R) + 1 : 7, q0 = after > 7 ? after : 7;
+            static_assert(NQ >= 20, "");
+            if (i == 1 && q >= q0 + 4 && q < q0 + 8) {
+                if (b + 1 < NB) {
+                    if (MASK) al.load4(act_load, row0 + 32 * (b + 1), q - q0 - 4);
+                } else if (NEXT_MASK) {
+                    al.load4(act_load, next_row0, q - q0 - 4);
+                }
+            }
             const bool mine = b >= 1, pend = PEND != 0 && b == 0;
             if (!mine && !pend) return;
             f32x16 &t = mine ? out[b >= 1 ? b - 1 : 0] : Breg[7];
             const bool masked = mine ? MASK : PEND == 1;
             if (q >= 1 && q <= 4) plain_push(scr, t[4 * (q - 1) + i], 4 * (q - 1) + i);
             if (q >= 5 && q <= 8) t[4 * (q - 5) + i] = relu_pull(scr, 4 * (q - 5) + i);
-            if (i == 0) {
-                const int R = b + 1 < NB ? ROUNDS : NEXT_ROUNDS;
-                const int after = R > 0 ? ((R - 1) * NQ) / (2 * R) + 1 : 7, q0 = after > 7 ? after : 7;
-                if (q >= q0 && q < q0 + 4) {   // mask (compare + select) and record four elements in one gap
-                    if (masked) {
+            if (i == 0 && q >= q0 && q < q0 + 4) {   // mask (compare + select) and record four elements in one gap
+                if (masked) {
 #pragma unroll
-                        for (int r = 4 * (q - q0); r < 4 * (q - q0) + 4; ++r) t[r] = tile_positive(act_prev[r]) ? t[r] : 0.0f;
-                    }
-                    rec.store4(mine ? row0 + 32 * (b - 1) : pend_row0, t, q - q0);
+                    for (int r = 4 * (q - q0); r < 4 * (q - q0) + 4; ++r) t[r] = tile_positive(act_prev[r]) ? t[r] : 0.0f;
                 }
+                rec.store4(mine ? row0 + 32 * (b - 1) : pend_row0, t, q - q0);
             }
         };
         if (b + 1 < NB) slice_step_early<KIND, K, ROUNDS, K>(wsrc, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
         else slice_step_early<KIND, K, NEXT_ROUNDS, NEXT_K>(wsrc, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
-        if (MASK) act_prev = act_this;
+        act_prev = act_hold;
+        act_hold = act_load;
     }
-    if (MASK) act_pend = act_prev;
+    act_pend = act_prev;
+    act_first = act_hold;
 }
 
 template <bool DEPTH>
@@ -530,27 +558,27 @@ __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_bwd_data_kernel)(cons
     rec.acts = deltas;
     rec.ld = (size_t)ld;
     rec.begin_tile(blockIdx.x, wave, j, h);
-    f32x16 act_pend = {};
+    f32x16 act_pend = {}, act_first = {};
 #define NEXT_STEP() _Pragma("unroll") for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     // d1: d(feat) = W_dir[:, :256]^T d(dir hidden) + W_alpha^T d(raw)[3]; fc_feat has no activation
-    step_bwd_early<11, 160, 8, 256, 0, false, 0>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, ROW_FEAT, 0, tid, lane);
+    step_bwd_early<11, 160, 8, 256, 0, false, 0, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, ROW_FEAT, 0, 256 * 7, tid, lane);
     NEXT_STEP();
     // d2..d9: d(h_l) = W_{l+1}^T d(h_{l+1}) * relu'(h_l),  l = 7..0 (straight-line: one step's tiles ARE the next one's B operands)
-    step_bwd_early<1, 256, 8, 256, 0, true, 2>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 7, ROW_FEAT + 224, tid, lane);
+    step_bwd_early<1, 256, 8, 256, 0, true, 2, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, 256 * 7, ROW_FEAT + 224, 256 * 6, tid, lane);
     NEXT_STEP();
-    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 6, 256 * 7 + 224, tid, lane);
+    step_bwd_early<1, 256, 8, 256, 0, true, 1, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, 256 * 6, 256 * 7 + 224, 256 * 5, tid, lane);
     NEXT_STEP();
-    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 5, 256 * 6 + 224, tid, lane);
+    step_bwd_early<1, 256, 8, 256, 0, true, 1, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, 256 * 5, 256 * 6 + 224, 256 * 4, tid, lane);
     NEXT_STEP();
-    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 4, 256 * 5 + 224, tid, lane);
+    step_bwd_early<1, 256, 8, 256, 0, true, 1, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, 256 * 4, 256 * 5 + 224, 256 * 3, tid, lane);
     NEXT_STEP();
-    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 3, 256 * 4 + 224, tid, lane);
+    step_bwd_early<1, 256, 8, 256, 0, true, 1, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, 256 * 3, 256 * 4 + 224, 256 * 2, tid, lane);
     NEXT_STEP();
-    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 2, 256 * 3 + 224, tid, lane);
+    step_bwd_early<1, 256, 8, 256, 0, true, 1, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, 256 * 2, 256 * 3 + 224, 256 * 1, tid, lane);
     NEXT_STEP();
-    step_bwd_early<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 256 * 1, 256 * 2 + 224, tid, lane);
+    step_bwd_early<1, 256, 8, 256, 0, true, 1, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, 256 * 1, 256 * 2 + 224, 0, tid, lane);
     NEXT_STEP();
-    step_bwd_early<1, 256, 8, 0, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, al, rec, 0, 256 * 1 + 224, tid, lane);
+    step_bwd_early<1, 256, 8, 0, 0, true, 1, false>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, 0, 256 * 1 + 224, 0, tid, lane);
 #undef NEXT_STEP
     // the last tile of the last step: nothing left to hide it behind
     {

@@ -127,6 +127,42 @@ __global__ __launch_bounds__(256, 1) void two_kernel(float *out, int iters, unsi
 // NV v_max_i32 behind every MFMA, the MFMAs rotating over NACC independent accumulators.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+// mix<NV, NL, NM>: v_mfma_f32_16x16x32_bf16 on four rotating accumulators with NV independent VALU instructions, NL ds_read_b128 and NM
+// scalar-base buffer-less global loads (NM = 2: one LDS-DMA piece instead) behind EVERY MFMA -- what one gap of the bf16 kernels can hold
+template <int NV, int NL, int NM>
+__global__ __launch_bounds__(256, 1) void mix_kernel(float *out, int iters, unsigned long long *stamps) {
+    __shared__ float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = i;
+    __syncthreads();
+    f32x4v acc4[4] = {};
+    float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f + threadIdx.x * 1e-4f;
+    bf16x8v ha, hb;
+    for (int i = 0; i < 8; ++i) ha[i] = (__bf16)(a + i), hb[i] = (__bf16)(b + i);
+    float x[4] = {a, b, a + b, a - b}, y[4] = {0, 0, 0, 0};
+    float4 dsv[2] = {}, gv = {};
+    const unsigned laddr = (threadIdx.x & 63) * 16;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(16384u));
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc4[s % 4]) : "v"(ha), "v"(hb));
+#pragma unroll
+            for (int k = 0; k < NV; ++k) asm volatile("v_max_i32 %0, 0, %1" : "=v"(y[k % 4]) : "v"(x[k % 4]));
+#pragma unroll
+            for (int k = 0; k < NL; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dsv[k % 2]) : "v"(laddr), "n"(1024 * (k % 2)));
+            if (NM == 1) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gv) : "v"(laddr), "s"(out + 256 * blockIdx.x));
+            if (NM == 2) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(laddr), "s"(out + 256 * blockIdx.x) : "memory");
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float sum = y[0] + y[1] + y[2] + y[3] + dsv[0].x + dsv[1].y + gv.x;
+    for (int n = 0; n < 4; ++n) sum += acc4[n][0];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+    if (threadIdx.x == 0) stamps[blockIdx.x] = t1 - t0;
+}
+
 template <int KIND, int NACC, int NV>
 __global__ __launch_bounds__(256, 1) void shape_kernel(float *out, int iters, unsigned long long *stamps) {
     f32x4v acc4[NACC] = {};
@@ -174,6 +210,7 @@ static int run(const char *name, F kernel, int iters, float *out, unsigned long 
     printf("%-28s %.3f ms, %.2f cycles per MFMA, %.1f TFLOP/s\n", name, ms, cyc / mf, mf * 4 * cus * 2.0 * 32 * 32 * 2 / (ms * 1e-3) / 1e12);
     return 0;
 }
+#define MIX(V, L, M) run("bf16 16x16x32 + valu " #V " ds_read " #L " vmem " #M, mix_kernel<V, L, M>, iters, out, st, cus)
 #define SHAPE(K, N, V) run("shape " #K " acc " #N " valu " #V, shape_kernel<K, N, V>, iters, out, st, cus)
 
 int main() {
@@ -220,6 +257,8 @@ int main() {
     printf("shapes: 0 = f32 16x16x4, 1 = bf16 16x16x32, 2 = bf16 32x32x16 (TFLOP/s column is for the f32 32x32x2 FLOP count: ignore)\n");
     SHAPE(0, 1, 0); SHAPE(0, 1, 1); SHAPE(0, 1, 2); SHAPE(0, 4, 0); SHAPE(0, 4, 1); SHAPE(0, 4, 2); SHAPE(0, 4, 4);
     SHAPE(1, 1, 0); SHAPE(1, 4, 0); SHAPE(1, 4, 1); SHAPE(1, 4, 2); SHAPE(1, 4, 3); SHAPE(1, 4, 4);
+    MIX(0, 0, 0); MIX(1, 0, 0); MIX(2, 0, 0); MIX(3, 0, 0); MIX(4, 0, 0); MIX(0, 1, 0); MIX(1, 1, 0); MIX(2, 1, 0); MIX(0, 2, 0); MIX(1, 2, 0);
+    MIX(0, 0, 1); MIX(1, 0, 1); MIX(1, 1, 1); MIX(0, 0, 2); MIX(1, 0, 2); MIX(1, 1, 2);
     SHAPE(2, 1, 0); SHAPE(2, 2, 0); SHAPE(2, 2, 1); SHAPE(2, 2, 2); SHAPE(2, 2, 4); SHAPE(2, 2, 8);
     return 0;
 }
