@@ -128,7 +128,7 @@ DDN_EXPORT int ddnerf_mlp_f32_pack(const float *params, int depth_head, float *p
 template <bool DEPTH>
 __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ packed, PackPlan pl,
                                                              float *__restrict__ raw, long M) {
-    __shared__ __attribute__((aligned(16))) float lds[F32_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[F32_FWD_LDS_FLOATS];
     mlp_f32_forward_tiles<DEPTH>(lds, feat, packed, 4u * (unsigned)pl.bias_off[0], raw, M, NoRecord{});
 }
 

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_fwd_train_kernel)(con
                                                                    const float *__restrict__ packed, FwdOffsets fo,
                                                                    float *__restrict__ raw, float *__restrict__ acts,
                                                                    long M, long ld) {
-    __shared__ __attribute__((aligned(16))) float lds[F32_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[F32_FWD_LDS_FLOATS];
     Recorder rec;
     rec.acts = acts;
     rec.ld = (size_t)ld;

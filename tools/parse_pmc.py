@@ -55,9 +55,12 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
                                      "view-direction columns again for the dir layer, one or two passes ahead of their use: re-reads of rows this workgroup "
                                      "fetched 50 us earlier, served by the L2 / MALL when they are still there and counted here when not; plus the packed weight "
                                      "image (1.4 MB per XCD) and write granularity.  At the measured launch time the total is < 15 % of HBM bandwidth" if mlp in ("bf16", "fp16") else
-                                     "by design the fp32 / x3 kernels re-read the 96 xyz feature columns for the skip layer instead of holding 48 registers "
-                                     "across four layers (+201 MB if it misses L2), and every 128-sample tile streams the whole weight image (2.6 MB) through L2; "
-                                     "at the measured launch time this is < 2 % (fp32) / < 6 % (x3) of HBM bandwidth"),
+                                     ("the fp32 kernel keeps its tile's xyz feature columns in LDS for the skip layer and reads the features non-temporally (round 4: 692 -> 400 MB); "
+                                      "what is left above the algorithmic bytes is the weight image (2.4 MB) streaming through eight L2s once per 128-sample tile "
+                                      "and the counter's conservative 2x correction; at the measured launch time < 2 % of HBM bandwidth" if mlp == "fp32" else
+                                      "by design the x3 kernel re-reads the 96 xyz feature columns for the skip layer instead of holding 48 registers "
+                                      "across four layers (+201 MB if it misses L2), and every 128-sample tile streams the whole weight image through L2; "
+                                      "at the measured launch time this is < 6 % of HBM bandwidth")),
            "kernels": table}
     json.dump(out, open(os.path.join(R, "profiles", ROUND + "_hbm_traffic_%s.json" % mlp), "w"), indent=1)
     print(mlp, "traffic MB", traffic / 1e6, "algorithmic MB", algo / 1e6)
