@@ -388,6 +388,9 @@ struct ActLoader {
     __amdgpu_buffer_rsrc_t rs;
     unsigned voff;
     __device__ __forceinline__ void begin_tile(long tile, int wave, int j, int h) {
+#ifdef F32_EXP_SMALLLOAD   // (diagnostic builds: the activation records of two tiles per XCD serve every tile: the fetches stay in L2)
+        tile = blockIdx.x & 15;
+#endif
         rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const unsigned *)acts + (size_t)tile * 8 * Recorder::kBlockWords), 0, 8 * Recorder::kBlockWords * 4, 0x00020000);
 #if F32_REC == 2
         voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * Recorder::kBlockWords + 2u * h * 16u + (j & 15));

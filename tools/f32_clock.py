@@ -20,7 +20,7 @@ K = [96] * 8 + [256] * 32 + [352] * 8 + [256] * 24 + [288] * 5 + [128]
 def build(defs):
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-function"]
-                          + defs + ["-shared", os.path.join(CSRC, "mlp_f32.hip"), os.path.join(CSRC, "mlp_f32_train_rec.hip"), "-o", SO])
+                          + defs + ["-shared", os.path.join(CSRC, "mlp_f32.hip"), os.path.join(CSRC, "mlp_f32_train.hip"), os.path.join(CSRC, "mlp_f32_train_rec.hip"), "-o", SO])
     print(SO)
 
 
@@ -59,7 +59,10 @@ def time_train(names):
     nin = [96, 256, 256, 256, 256, 352, 256, 256, 256, 256, 283, 128, 128]
     params = torch.randn(sum(o * i + o for o, i in zip(nout, nin)), device="cuda") * 0.05
     acts = torch.empty(2560, M, device="cuda")
+    deltas = torch.empty(2560, M, device="cuda")
+    graw = torch.randn(M, 6, device="cuda")
     raw = torch.empty(M, 6, device="cuda")
+    resb = {}
     for rep in range(4):
         for nm, lib in libs.items():
             n = lib.ddnerf_mlp_f32_packed_floats
@@ -77,7 +80,23 @@ def time_train(names):
             e1.record()
             torch.cuda.synchronize()
             res.setdefault(nm, []).append(e0.elapsed_time(e1) / 10)
+            nt = lib.ddnerf_mlp_f32_packed_t_floats
+            nt.restype = ctypes.c_size_t
+            packed_t = torch.empty(nt(1), device="cuda")
+            assert lib.ddnerf_mlp_f32_pack_t(P(params.data_ptr()), 1, P(packed_t.data_ptr()), None) == 0
+            gob = lambda: lib.ddnerf_mlp_f32_backward_data_rec(P(graw.data_ptr()), P(packed_t.data_ptr()), P(acts.data_ptr()), 1, P(deltas.data_ptr()),
+                                                               ctypes.c_long(M), ctypes.c_long(M), None)
+            for _ in range(3):
+                assert gob() == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                gob()
+            e1.record()
+            torch.cuda.synchronize()
+            resb.setdefault(nm, []).append(e0.elapsed_time(e1) / 10)
     for nm in names:
+        print("%-12s backward_data_rec %.4f ms per launch (median of 4 x 10)  [%s]" % (nm, sorted(resb[nm])[2], " ".join("%.4f" % v for v in resb[nm])))
         print("%-12s forward_train_rec %.4f ms per launch (median of 4 x 10)  [%s]" % (nm, sorted(res[nm])[2], " ".join("%.4f" % v for v in res[nm])))
 
 
