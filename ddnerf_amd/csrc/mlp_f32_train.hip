@@ -597,6 +597,9 @@ DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_backward_data)(const float *g_raw, const 
     DDN_REQUIRE(g_raw && packed_t && acts && deltas, DDNERF_E_ARG);
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ld >= M && ld % 128 == 0, DDNERF_E_RANGE);
+#ifndef F32_REC
+    DDN_REQUIRE(ld <= (1l << 27), DDNERF_E_RANGE);  // (the fp32 matrices' 32-bit store offsets: 20 ld bytes)
+#endif
     DDN_REQUIRE(ddn_aligned(packed_t, 16), DDNERF_E_ALIGN);
     const unsigned packed_bytes = 4u * (unsigned)make_plan_t(depth_head).total;
     dim3 grid((unsigned)((M + 127) / 128));
