@@ -7,6 +7,8 @@
 //   mode 2: + the kernels' weight staging: one 1-KiB LDS-DMA piece per wave per 24 MFMAs from a 1.4 MB image (L2 hits) into four
 //           36-KiB slots, one s_barrier behind a counted s_waitcnt vmcnt (three barriers of lead) per 96 MFMAs (two-group kernel: one piece per 24.8, one
 //           barrier per 117)
+//   mode 3 / 4: modes 1 / 2 with HALF the fragment reads (one ds_read_b128 per EIGHT MFMAs): what a body whose two sample groups walk a
+//           weight chunk in lockstep -- every A fragment feeding both groups' MFMAs -- would be up against
 // Operands: uniform(-1, 1) bf16 (the caller fills `src`).  Every workgroup reports d(s_memtime), d(s_memrealtime).
 #include "mlp_bf16_common.h"
 
@@ -16,7 +18,7 @@ typedef float cf32x4 __attribute__((ext_vector_type(4)));
 #define CEIL_SLOT (36 * 1024)
 #define CEIL_IMG (1408 * 1024)   // bytes of `src` a mode-2 loop streams (a multiple of 4 KiB; the MLP's packed image is 1.36 MiB)
 
-template <int MODE>
+template <int MODE, bool HALF = false>
 __global__ __launch_bounds__(256, 1) void mfma_ceiling_kernel(const char *__restrict__ src, float *__restrict__ out, int iters,
                                                               unsigned long long *__restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) char lds[4 * CEIL_SLOT];
@@ -39,9 +41,12 @@ __global__ __launch_bounds__(256, 1) void mfma_ceiling_kernel(const char *__rest
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int s = 0; s < 24; ++s) {   // 24 k-steps x 4 MFMAs = 96 MFMAs per iteration
-            const cbf16x8 av = a[s & 3];
+            const cbf16x8 av = HALF ? a[(s >> 1) & 3] : a[s & 3];
             // (a scalar base per iteration + an immediate per k-step: no address arithmetic beside the MFMAs)
-            if constexpr (MODE >= 1) a[(s + 3) & 3] = *(const cbf16x8 *)(lds + (it & 3) * (24 * 1024) + s * 1024 + 16 * lane);
+            if constexpr (MODE >= 1 && !HALF) a[(s + 3) & 3] = *(const cbf16x8 *)(lds + (it & 3) * (24 * 1024) + s * 1024 + 16 * lane);
+            if constexpr (MODE >= 1 && HALF) {
+                if ((s & 1) == 0) a[((s >> 1) + 3) & 3] = *(const cbf16x8 *)(lds + (it & 3) * (24 * 1024) + s * 1024 + 16 * lane);
+            }
             if constexpr (MODE == 2) {
                 if (s % 6 == 0) {   // one piece per 24 MFMAs; the four pieces of an iteration share ONE (M0, source base) pair and differ in
                                     // the immediate offset, which applies to both addresses -- the kernels' form (a piece = one instruction)
@@ -85,11 +90,13 @@ __global__ __launch_bounds__(256, 1) void mfma_ceiling_kernel(const char *__rest
 // a wave issues iters x 96 MFMAs (16 x 16 x 32 x 2 FLOP each, four waves per workgroup).
 DDN_EXPORT int ddnerf_debug_mfma_ceiling(int mode, const void *src, float *out, int iters, unsigned long long *stamps, ddnerf_stream_t stream) {
     DDN_REQUIRE(src && out && stamps && iters > 0, DDNERF_E_ARG);
-    DDN_REQUIRE(mode >= 0 && mode <= 2, DDNERF_E_RANGE);
+    DDN_REQUIRE(mode >= 0 && mode <= 4, DDNERF_E_RANGE);
     const dim3 grid((unsigned)ddn_cu_count());
     if (mode == 0) hipLaunchKernelGGL(mfma_ceiling_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const char *)src, out, iters, stamps);
     if (mode == 1) hipLaunchKernelGGL(mfma_ceiling_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const char *)src, out, iters, stamps);
     if (mode == 2) hipLaunchKernelGGL(mfma_ceiling_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const char *)src, out, iters, stamps);
+    if (mode == 3) hipLaunchKernelGGL((mfma_ceiling_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, (const char *)src, out, iters, stamps);
+    if (mode == 4) hipLaunchKernelGGL((mfma_ceiling_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, (const char *)src, out, iters, stamps);
     return ddn_launch_status();
 }
 DDN_EXPORT size_t ddnerf_debug_mfma_ceiling_src_bytes(void) { return (size_t)CEIL_IMG + 128 * 1024; }
