@@ -118,6 +118,34 @@ def test_mlp_f32_persistent_tiles(ops):
         assert np.abs(a[0:256, k] - h0).max() <= 1e-5 * max(1.0, np.abs(h0).max()), c
 
 
+def test_mlp_f32_many_launches_stay_identical(ops):
+    """The fp32 kernels hand data from slice to slice and tile to tile through LDS on ONE barrier per slice (a tile's first fragments
+    and bias tile are read behind the barrier of the slice before; activations and deltas ride through a per-wave scratch area without
+    any): 40 back-to-back launches of the forward, the record-writing training forward and its backward at the benchmark's fine-pass
+    size must reproduce the first launch bit for bit -- a missing wait or a misplaced barrier shows up as a rare differing row."""
+    M, depth = 4096 * 128, True
+    g = torch.Generator(device="cuda").manual_seed(3)
+    feat = torch.zeros(M, 128, device="cuda")
+    feat[:, :123] = torch.rand(M, 123, device="cuda", generator=g) * 2 - 1
+    flat = dev(flat_params(synthetic.make_state_dict(depth, 5, 4.0), depth))
+    packed, packed_t = ops.mlp_f32_pack(flat, depth), ops.mlp_f32_pack_t(flat, depth)
+    G = torch.randn(M, 6, device="cuda", generator=g)
+    raw0 = ops.mlp_f32_forward(feat, packed, depth).clone()
+    raw_t0, rec0 = ops.mlp_f32_forward_train(feat, packed, depth, rec=True)
+    raw_t0, rec0 = raw_t0.clone(), rec0.clone()
+    blocks = lambda t, rows: t.view(torch.int32).reshape(-1, 2560, 16)[:, :rows]    # (the rows a record defines: the rest is never written)
+    d0 = blocks(ops.mlp_f32_backward_data(G, packed_t, rec0, depth, rec=True), 2438).clone()
+    rec0 = blocks(rec0, 2555).clone()
+    assert torch.equal(raw0, raw_t0)
+    for it in range(40):
+        assert torch.equal(ops.mlp_f32_forward(feat, packed, depth), raw0), it
+        if it % 4 == 0:
+            raw_t, rec = ops.mlp_f32_forward_train(feat, packed, depth, rec=True)
+            assert torch.equal(raw_t, raw0) and torch.equal(blocks(rec, 2555), rec0), it
+            assert torch.equal(blocks(ops.mlp_f32_backward_data(G, packed_t, rec, depth, rec=True), 2438), d0), it
+            del raw_t, rec
+
+
 def test_dd_records_match_boolean_indexing(ops):
     """ops.dd_records (three small kernels) against the reference's expression pdf = w / w.sum(-1); x[pdf > 0.1] evaluated by
     torch on the CPU (ATen's summation order), incl. an all-zero row (NaN pdf: nothing selected) and ragged widths"""
