@@ -493,8 +493,8 @@ __device__ __forceinline__ void step_bwd_early(__amdgpu_buffer_rsrc_t wsrc, unsi
                 rec.store4(mine ? row0 + 32 * (b - 1) : pend_row0, t, q - q0);
             }
         };
-        if (b + 1 < NB) slice_step_early<KIND, K, ROUNDS, K>(wsrc, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
-        else slice_step_early<KIND, K, NEXT_ROUNDS, NEXT_K>(wsrc, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
+        if (b + 1 < NB) slice_step_early<KIND, K, ROUNDS, K, false>(wsrc, nullptr, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
+        else slice_step_early<KIND, K, NEXT_ROUNDS, NEXT_K, false>(wsrc, nullptr, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
         act_prev = act_hold;
         act_hold = act_load;
     }

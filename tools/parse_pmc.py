@@ -55,7 +55,7 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
                                      "view-direction columns again for the dir layer, one or two passes ahead of their use: re-reads of rows this workgroup "
                                      "fetched 50 us earlier, served by the L2 / MALL when they are still there and counted here when not; plus the packed weight "
                                      "image (1.4 MB per XCD) and write granularity.  At the measured launch time the total is < 15 % of HBM bandwidth" if mlp in ("bf16", "fp16") else
-                                     ("the fp32 kernel keeps its tile's xyz feature columns in LDS for the skip layer and reads the features non-temporally (round 4: 692 -> 400 MB); "
+                                     ("the fp32 kernel keeps its tile's xyz feature columns in LDS for the skip layer and reads the features non-temporally, its weight slices travel by LDS-DMA (round 4: 692 -> 320 MB); "
                                       "what is left above the algorithmic bytes is the weight image (2.4 MB) streaming through eight L2s once per 128-sample tile "
                                       "and the counter's conservative 2x correction; at the measured launch time < 2 % of HBM bandwidth" if mlp == "fp32" else
                                       "by design the x3 kernel re-reads the 96 xyz feature columns for the skip layer instead of holding 48 registers "
