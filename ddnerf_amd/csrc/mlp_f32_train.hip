@@ -173,6 +173,7 @@ __device__ __forceinline__ unsigned rec_word(float x) {
 }
 // two at once, 3.5 instructions per element: both hi parts by one v_cvt_pk_bf16_f32, a shift / mask back to fp32, the subtraction, and one
 // v_cvt_pk_bf16_f32 per word (its high half converts hi's fp32 image, exactly, its low half rounds lo) -- the words rec_word gives
+typedef unsigned u32x4_rec __attribute__((ext_vector_type(4)));
 typedef __bf16 rw_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float rw_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void rec_word2(float x0, float x1, unsigned &w0, unsigned &w1) {
@@ -223,6 +224,13 @@ __device__ __forceinline__ bool tile_positive(float a) { return a > 0.0f; }
 
 struct Recorder {
     static constexpr bool kActive = true;
+#if defined(F32_REC) && F32_REC == 1 && !defined(F32_EXP_NOQUADS)   // (F32_EXP_NOQUADS: diagnostic build with the 4-byte stores)
+    static constexpr bool kQuads = true;   // hi/lo words: one word per value, four consecutive samples of a row = 16 contiguous bytes
+    unsigned voff_t;                       // this lane's byte offset for a quad (mlp_f32_fwd.inc: the transposed read of the scratch)
+#else
+    static constexpr bool kQuads = false;
+    __device__ __forceinline__ void store_quad(int, int, f32x4) {}
+#endif
     float *acts;
     size_t ld;
 #ifdef F32_REC
@@ -242,8 +250,25 @@ struct Recorder {
         voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * kBlockWords + 2u * h * 16u + (j & 15));
 #else
         voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * kBlockWords + 4u * h * 16u + (j & 15));
+#ifndef F32_EXP_NOQUADS
+        const unsigned L = 32u * h + j;   // quad i of lane L: row 8 i + (L >> 4) + 4 ((L >> 3) & 1), samples 4 (L & 7) .. + 3 of the wave's 32
+        voff_t = 4u * ((unsigned)(wave * 2 + ((L & 7) >> 2)) * kBlockWords + ((L >> 4) + 4u * ((L >> 3) & 1)) * 16u + 4u * (L & 3));
+#endif
 #endif
     }
+#if F32_REC == 1 && !defined(F32_EXP_NOQUADS)
+    __device__ __forceinline__ void store_quad(int row0, int i, f32x4 x) {
+        unsigned w0, w1, w2, w3;
+        rec_word2(x.x, x.y, w0, w1);
+        rec_word2(x.z, x.w, w2, w3);
+        const u32x4_rec w = {w0, w1, w2, w3};
+#ifdef F32_EXP_NOSTORE
+        asm volatile("" ::"v"(w));
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, voff_t, 64u * (row0 + 8 * i), 0);
+#endif
+    }
+#endif
     // registers 4g .. 4g+3 of a tile = its rows 8g .. 8g+3 (+ 4h)
     __device__ __forceinline__ void store4(int row0, const f32x16 &v, int g) {
 #if F32_REC == 2
@@ -490,6 +515,8 @@ __device__ __forceinline__ void step_bwd_early(__amdgpu_buffer_rsrc_t wsrc, unsi
 #pragma unroll
                     for (int r = 4 * (q - q0); r < 4 * (q - q0) + 4; ++r) t[r] = tile_positive(act_prev[r]) ? t[r] : 0.0f;
                 }
+                // (4-byte stores here: the forward's 16-byte form -- the masked tile written back into the scratch, read transposed, stored as
+                // quads a few chunks later -- measured 2.8 % SLOWER in this kernel, 4.91 against 4.77 ms)
                 rec.store4(mine ? row0 + 32 * (b - 1) : pend_row0, t, q - q0);
             }
         };
