@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Where the fp32 MLP kernel's non-MFMA cycles go: clock stamps per weight slice.
 
+(The per-slice stamp build, -DF32_STAMP, keeps a 4-byte index in LDS: since the forward parks its xyz columns there it uses exactly the
+CU's 160 KB and that build no longer links -- its numbers in profiles/r04_f32_fwd_experiments.log are of the kernels before that step.
+The tile-level build, -DF32_STAMP_TILE, and the ingredient builds, -DF32_EXP_*, are unaffected.)
+
     python tools/f32_clock.py build [-DNAME ...]   (CPU: tools/lib/f32_stamp.so = mlp_f32.hip + api-free, -DF32_STAMP and any extra defines)
     python tools/f32_clock.py run                  (GPU box: one fine-pass launch, per-slice table from 64 workgroups)
 
