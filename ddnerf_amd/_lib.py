@@ -31,6 +31,10 @@ _SIGS = {
     "ddnerf_mlp_bf16g2_packed_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_bf16g2_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_bf16g2_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
+    "ddnerf_ray_table_bytes": (C.c_size_t, [C.c_int]),
+    "ddnerf_ray_table": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
+    "ddnerf_encode_mlp_bf16_scratch_bytes": (C.c_size_t, []),
+    "ddnerf_encode_mlp_bf16_forward": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_f16_packed_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_f16_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_f16_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),

@@ -128,6 +128,23 @@ def _scan(ins):
                     bad.append("MFMA write -> read, %d apart:\n    %s\n    %s" % (dist + 1, text, ins[j][2]))
             dist += slots[j]
             j += 1
+    # The fused body (gen_bf16_g2.py, Gen(fused=True)) carries an encoder: transcendentals and IEEE divisions.  Two gfx940-family
+    # rules hipcc pads for and nothing pads inside asm: a transcendental's result may not be read by the VALU instruction issued right
+    # behind it (one wait state), and v_div_fmas reads the VCC a VALU instruction wrote no less than four wait states earlier.
+    TRANS = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32")
+    for i, (m, o, text) in enumerate(ins):
+        if m in TRANS and i + 1 < len(ins):
+            mj = ins[i + 1][0]
+            if mj.startswith("v_") and mj not in TRANS and du[i + 1][1] & du[i][0]:
+                bad.append("transcendental result read by the next instruction:\n    %s\n    %s" % (text, ins[i + 1][2]))
+        if m.startswith("v_div_fmas"):
+            dist, j = 0, i - 1
+            while j >= 0 and dist < 4:
+                mj, oj = ins[j][0], ins[j][1]
+                if mj.startswith("v_") and any(x.strip() == "vcc" for x in oj[:2]) and not mj.startswith("v_div_fmas"):
+                    bad.append("VALU write of vcc -> v_div_fmas, %d apart:\n    %s\n    %s" % (dist + 1, ins[j][2], text))
+                dist += slots[j]
+                j -= 1
     return len([1 for m, _, _ in ins if m.startswith("v_mfma")]), bad
 
 

@@ -26,6 +26,7 @@ fetched again (L2 / MALL hits) into registers that are idle at that point, one o
 less lead is group 1's xyz block: T is busy with group 0's until the last k-steps of pass (5, g0), ten k-steps before group 1's first
 block wants it (the k-steps of a block keep the one-group kernel's order: the two kernels are bit-identical)."""
 import os
+import struct
 import sys
 from collections import defaultdict
 
@@ -109,6 +110,37 @@ STAMP_BLOCKS = (8, 20)
 set_experiment({})
 FEAT_ROW = 256   # bytes of one encoded sample (DDNERF_FEAT_LD bf16)
 TILE = 512
+# ---- the FUSED body (Gen(fused=True), mlp_bf16_g2e.hip): cast_rays + integrated_pos_enc inside the MLP kernel ------------------------------
+# (reference stage: models/models.py:117-142 -- cast_rays, integrated_pos_enc, the view-direction columns and the MLP are ONE step there).
+# The encoded feature rows never exist in HBM.  Inputs are the fenceposts t_vals [n, S+1] and a per-RAY table (128 B: o, d, radius^2,
+# d^2, 1 - d^2/|d|^2 as fp32, then the ray's 32 view-direction columns as one k-order 16-bit row), S a multiple of 64 so that a group
+# of 64 samples (one sample per lane) lies on one ray.  While layers 6 - 8 run -- T[c][1..2], 32 registers, are idle there -- the VALU
+# gaps of the MFMA stream encode the NEXT tile's two groups, lane = sample: the Gaussian of the sample's interval (the arithmetic of
+# rays_encode.hip's gaussian_of_interval / encode_kernel<1>, operation for operation: IEEE divisions, no contraction), then per (octave,
+# axis) the damping 2^(-0.5 cov 4^d log2 e) and the sine and cosine on the hardware transcendentals, 16-bit pairs, and every four
+# columns one 8-byte store into the workgroup's private scratch rows (512 rows x 192 B, written and re-read every tile: L2-resident).
+# Everything that used to fetch a feature row fetches a scratch row instead -- the next tile's layer-0 inputs during pass 9, the skip
+# layer's xyz columns at layers 4 / 5 --; the view-direction k-step comes from the ray table.  Bit-identical to encode_kernel<1>
+# followed by the unfused body (tests/test_hip_fused_mlp.py).
+ENC_ROW = 192
+V_EP = [128 + 12 * c + 4 + i for c in range(4) for i in range(8)]    # the encoder's 32 temporaries: T[c][1..2]
+V_ET = {0: (254, 255), 1: (247, 253)}                                # fenceposts t0, t1 of the next tile's groups (fetched in pass (5, g1))
+S_RAY = {0: 48, 1: 64}                                               # s[48:63], s[64:79]: the ray-table rows of the next tile's groups
+S_E0, S_E1, S_E2, S_E3 = 80, 81, 82, 83
+S_GB = 46                                                            # s46, s47: scratch byte offsets of this wave's two groups
+S_CT, S_GC = 92, 93                                                  # 100 pi (safe_sin's period); group index of this tile's first group
+# asm operands of the fused body: %0 scratch rows of this workgroup (buffer resource)  %1 outputs  %2 %3 weight image  %4 LDS base  %5 wave
+#   %6 tile  %7 grid  %8 first tile  %9 t_vals (buffer resource)  %10 ray table (buffer resource)  %11 S + 1  %12 ceil(2^31 / (S / 64))
+#   %13 n - 1  %14 S / 64  %15 ray table (64-bit address)
+
+
+def lit(x):
+    """a float as the 32-bit literal of a VOP2 / SOP1 instruction"""
+    return "0x%08x" % struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def f32(x):
+    return struct.unpack("<f", struct.pack("<f", x))[0]
 
 
 def rowb(k):
@@ -247,8 +279,8 @@ def acc(par, c):
 
 
 class Gen:
-    def __init__(self, depth_head, stamp, carry=None):
-        self.depth_head, self.stamp = depth_head, stamp
+    def __init__(self, depth_head, stamp, carry=None, fused=False):
+        self.depth_head, self.stamp, self.fused = depth_head, stamp, fused
         self.rs = 24 if depth_head else 16          # bytes of one output row
         self.out = []
         self.vm = list(carry["vm"]) if carry else []        # outstanding vector-memory loads: (serial, "dma" | "x")
@@ -257,6 +289,7 @@ class Gen:
         self.last_piece = dict(carry["last_piece"]) if carry else {}   # chunk load (index in `real`) -> serial of its last LDS-DMA piece
         self.lg = []                                        # outstanding LDS reads (keys)
         self.nmfma = 0
+        self.enc_held, self.enc_stream = [], []             # fused body: encoder stores waiting for the first half of a period
 
     def e(self, s):
         self.out.append("\t" + s)
@@ -324,11 +357,212 @@ class Gen:
         """16 bytes of the feature row of sample (this / next tile, group g, column block c, this lane's row): 32-column group q.
         The row offset goes through the bounds-checked voffset: rows past the end read as zero (their outputs are never stored)."""
         kind, r = dst
+        if self.fused:      # (the workgroup's scratch rows: one buffer, this tile's or the next one's according to WHEN the fetch runs)
+            if q == 3:
+                return self.dir_load(dst, g, key)
+            self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, (g * 64 + c * 16) * ENC_ROW))
+            self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
+            self.e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d sc1" % (reg(kind, r, 4), V_TMP1, 64 * q))
+            self.vm_issue("x", key)
+            return
         self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, (g * 64 + c * 16) * FEAT_ROW))
         self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
         if not NOX:
             self.e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d%s" % (reg(kind, r, 4), V_TMP1, 64 * q, XPOLICY))
         self.vm_issue("x", key)
+
+    def ray_of_group(self, sreg, cur, g, emit=None):
+        """sreg <- ray index of group g of this / the next tile (groups of 64 samples; S / 64 groups per ray), unclamped"""
+        e = emit or self.e
+        e("s_add_u32 s%d, s%d, %d" % (sreg, S_GC if cur else S_TBN, g))
+        e("s_lshl_b32 s%d, s%d, 1" % (sreg, sreg))
+        e("s_mul_hi_u32 s%d, s%d, %%12" % (sreg, sreg))
+
+    def dir_load(self, dst, g, key):
+        """the view-direction k-step of group g of THIS tile: 16 bytes of the ray's k-order row per lane (lane group lg: bytes 16 lg ..)"""
+        kind, r = dst
+        self.ray_of_group(S_T0, True, g)
+        self.e("s_min_u32 s%d, s%d, %%13" % (S_T0, S_T0))
+        self.e("s_lshl_b32 s%d, s%d, 7" % (S_T0, S_T0))
+        self.e("buffer_load_dwordx4 %s, v%d, %%10, s%d offen offset:64" % (reg(kind, r, 4), V_LG16, S_T0))
+        self.vm_issue("x", key)
+
+    # ---- the encoder of the fused body
+    def enc_fetch_ops(self, cur, g, tregs=None):
+        """what a group's encoder reads: its ray's table row -> s[S_RAY[g]..+15], its samples' fenceposts -> tregs (lane = sample)"""
+        t0, t1 = tregs or V_ET[g]
+        ops = []
+        add = lambda s_: ops.append(("i", s_))
+        self.ray_of_group(S_E1, cur, g, add)
+        add("s_add_u32 s%d, s%d, %d" % (S_E0, S_GC if cur else S_TBN, g))
+        add("s_mul_i32 s%d, s%d, %%14" % (S_E2, S_E1))
+        add("s_sub_u32 s%d, s%d, s%d" % (S_E2, S_E0, S_E2))
+        add("s_lshl_b32 s%d, s%d, 6" % (S_E2, S_E2))                       # first sample of the group on its ray
+        add("s_mul_i32 s%d, s%d, %%11" % (S_E3, S_E1))
+        add("s_add_u32 s%d, s%d, s%d" % (S_E3, S_E3, S_E2))
+        add("s_lshl_b32 s%d, s%d, 2" % (S_E3, S_E3))                       # byte offset of t_vals[ray][j0] (past the end: reads as zero)
+        add("s_min_u32 s%d, s%d, %%13" % (S_E1, S_E1))
+        add("s_lshl_b32 s%d, s%d, 7" % (S_E1, S_E1))
+        ops.append(("sload", "s_load_dwordx16 s[%d:%d], %%15, s%d" % (S_RAY[g], S_RAY[g] + 15, S_E1)))
+        add("v_lshrrev_b32 v%d, 2, v%d" % (V_TMP1, V_LANE16))
+        ops.append(("tload", "buffer_load_dword v%d, v%d, %%9, s%d offen" % (t0, V_TMP1, S_E3), ("t", g, 0)))
+        ops.append(("tload", "buffer_load_dword v%d, v%d, %%9, s%d offen offset:4" % (t1, V_TMP1, S_E3), ("t", g, 1)))
+        return ops
+
+    def enc_unit_ops(self, g, tregs=None):
+        """the encoder of one group of 64 samples (lane = sample) as a list of single instructions: ("i", text) plain, ("tneed", g)
+        wait for the fenceposts, ("sflush",) wait for the ray row, ("store", text, pair) an 8-byte store of four columns.
+        Arithmetic: rays_encode.hip gaussian_of_interval (cone) and encode_kernel<1> phase 2, operation for operation."""
+        t0, t1 = tregs or V_ET[g]
+        R = S_RAY[g]
+        P = list(V_EP)
+        ops = []
+        I = lambda s_: ops.append(("i", s_))
+        v = lambda r: "v%d" % r
+        mean, cov = P[0:3], P[3:6]
+        vrow = P[6]
+        w = P[7:20]            # the Gaussian's temporaries; the value chain reuses them
+        packs = [(P[20 + 2 * i], P[21 + 2 * i]) for i in range(6)]
+
+        def div(q, a, b, tmp):
+            """q = a / b, correctly rounded (the sequence the compiler emits for an fp32 division with denormals on); tmp: 4 registers"""
+            ds, ns, r, e = tmp
+            I("v_div_scale_f32 %s, vcc, %s, %s, %s" % (v(ds), v(b), v(b), v(a)))
+            I("v_rcp_f32 %s, %s" % (v(r), v(ds)))
+            I("v_div_scale_f32 %s, vcc, %s, %s, %s" % (v(ns), v(a), v(b), v(a)))     # (the LAST writer of vcc in front of v_div_fmas)
+            I("v_fma_f32 %s, -%s, %s, 1.0" % (v(e), v(ds), v(r)))
+            I("v_fma_f32 %s, %s, %s, %s" % (v(r), v(e), v(r), v(r)))
+            I("v_mul_f32 %s, %s, %s" % (v(q), v(ns), v(r)))
+            I("v_fma_f32 %s, -%s, %s, %s" % (v(e), v(ds), v(q), v(ns)))
+            I("v_fma_f32 %s, %s, %s, %s" % (v(q), v(e), v(r), v(q)))
+            I("v_fma_f32 %s, -%s, %s, %s" % (v(e), v(ds), v(q), v(ns)))
+            I("v_div_fmas_f32 %s, %s, %s, %s" % (v(q), v(e), v(r), v(q)))
+            I("v_div_fixup_f32 %s, %s, %s, %s" % (v(q), v(q), v(b), v(a)))
+
+        mu, hw, mu2, hw2, hw4, den, a_, q1, three = w[0:9]
+        tmp = w[9:13]
+        tm, tv, rv = mean[0], mean[1], mean[2]        # (t_mean, t_var, r_var live in the mean registers until mean / cov are formed)
+        ops.append(("tneed", g))
+        I("v_mul_u32_u24 %s, 12, v%d" % (v(vrow), V_LANE16))                         # lane * 192: the sample's scratch row
+        I("v_add_f32 %s, %s, %s" % (v(mu), v(t0), v(t1)))
+        I("v_sub_f32 %s, %s, %s" % (v(hw), v(t1), v(t0)))
+        I("v_mul_f32 %s, 0.5, %s" % (v(mu), v(mu)))                                  # (t0 + t1) / 2
+        I("v_mul_f32 %s, 0.5, %s" % (v(hw), v(hw)))                                  # (t1 - t0) / 2
+        I("v_mul_f32 %s, %s, %s" % (v(mu2), v(mu), v(mu)))
+        I("v_mul_f32 %s, %s, %s" % (v(hw2), v(hw), v(hw)))
+        I("v_mul_f32 %s, %s, %s" % (v(hw4), v(hw2), v(hw2)))
+        I("v_mul_f32 %s, %s, %s" % (v(den), lit(3.0), v(mu2)))
+        I("v_add_f32 %s, %s, %s" % (v(den), v(den), v(hw2)))                         # 3 mu^2 + hw^2
+        I("v_add_f32 %s, %s, %s" % (v(a_), v(mu), v(mu)))
+        I("v_mul_f32 %s, %s, %s" % (v(a_), v(a_), v(hw2)))                           # 2 mu hw^2
+        div(q1, a_, den, tmp)
+        I("v_add_f32 %s, %s, %s" % (v(tm), v(mu), v(q1)))                            # t_mean
+        I("v_mov_b32 %s, %s" % (v(three), lit(3.0)))
+        div(q1, hw2, three, tmp)                                                     # hw^2 / 3
+        I("v_mul_f32 %s, %s, %s" % (v(a_), lit(12.0), v(mu2)))
+        I("v_sub_f32 %s, %s, %s" % (v(a_), v(a_), v(hw2)))
+        I("v_mul_f32 %s, %s, %s" % (v(a_), v(hw4), v(a_)))                           # hw^4 (12 mu^2 - hw^2)
+        I("v_mul_f32 %s, %s, %s" % (v(three), v(den), v(den)))
+        div(mu, a_, three, tmp)                                                      # (mu is dead: mu^2 carries on)
+        I("v_mul_f32 %s, %s, %s" % (v(mu), lit(0.266666681), v(mu)))
+        I("v_sub_f32 %s, %s, %s" % (v(tv), v(q1), v(mu)))                            # t_var
+        I("v_mul_f32 %s, %s, %s" % (v(a_), lit(0.25), v(mu2)))                                # mu^2 / 4
+        I("v_mul_f32 %s, %s, %s" % (v(q1), lit(0.416666657), v(hw2)))
+        I("v_add_f32 %s, %s, %s" % (v(a_), v(a_), v(q1)))
+        I("v_mul_f32 %s, %s, %s" % (v(q1), lit(0.266666681), v(hw4)))
+        div(mu, q1, den, tmp)
+        I("v_sub_f32 %s, %s, %s" % (v(a_), v(a_), v(mu)))
+        ops.append(("sflush",))                                                      # the ray row (scalar memory returns out of order)
+        I("v_mul_f32 %s, s%d, %s" % (v(rv), R + 6, v(a_)))                           # r_var = radius^2 (...)
+        # cov_a = t_var d_a^2 + r_var (1 - d_a^2 / |d|^2);  mean_a = d_a t_mean + o_a   (two roundings each: no fma)
+        for a in range(3):
+            I("v_mul_f32 %s, s%d, %s" % (v(cov[a]), R + 7 + a, v(tv)))
+            I("v_mul_f32 %s, s%d, %s" % (v(w[a]), R + 10 + a, v(rv)))
+        for a in range(3):
+            I("v_add_f32 %s, %s, %s" % (v(cov[a]), v(cov[a]), v(w[a])))
+        for a in range(3):
+            I("v_mul_f32 %s, s%d, %s" % (v(w[a]), R + 3 + a, v(tm)))
+        for a in range(3):
+            I("v_add_f32 %s, s%d, %s" % (v(mean[a]), R + a, v(w[a])))
+        # the 48 (octave, axis) pairs in column order: column 3 d + a (sine), 48 + 3 d + a (cosine)
+        y, u, ts, tc, yc, hs, hc = w[0:7]
+        npack = 0
+        for col in range(48):
+            d, a = divmod(col, 3)
+            if d == 0:
+                ysrc = v(mean[a])
+            else:
+                I("v_mul_f32 %s, %s, %s" % (v(y), lit(float(1 << d)), v(mean[a])))
+                ysrc = v(y)
+            I("v_mul_f32 %s, %s, %s" % (v(u), lit(-0.5 * float(4 ** d) * f32(1.44269502)), v(cov[a])))
+            I("v_exp_f32 %s, %s" % (v(u), v(u)))
+            I("v_mul_f32 %s, %s, %s" % (v(ts), lit(0.0031830988), ysrc))
+            I("v_add_f32 %s, %s, %s" % (v(yc), lit(1.57079637), ysrc))
+            I("v_floor_f32 %s, %s" % (v(ts), v(ts)))
+            I("v_mul_f32 %s, %s, %s" % (v(tc), lit(0.0031830988), v(yc)))
+            I("v_fma_f32 %s, -%s, s%d, %s" % (v(ts), v(ts), S_CT, ysrc))
+            I("v_floor_f32 %s, %s" % (v(tc), v(tc)))
+            I("v_mul_f32 %s, %s, %s" % (v(ts), lit(0.15915494), v(ts)))
+            I("v_fma_f32 %s, -%s, s%d, %s" % (v(tc), v(tc), S_CT, v(yc)))
+            I("v_sin_f32 %s, %s" % (v(ts), v(ts)))
+            I("v_mul_f32 %s, %s, %s" % (v(tc), lit(0.15915494), v(tc)))
+            I("v_sin_f32 %s, %s" % (v(tc), v(tc)))
+            if col % 2 == 0:
+                I("v_mul_f32 %s, %s, %s" % (v(hs), v(u), v(ts)))
+                I("v_mul_f32 %s, %s, %s" % (v(hc), v(u), v(tc)))
+            else:
+                kk = col // 4
+                ps, pc = packs[npack % 6], packs[(npack + 1) % 6]
+                half = (col % 4) // 2
+                I("v_mul_f32 %s, %s, %s" % (v(ts), v(u), v(ts)))
+                I("v_mul_f32 %s, %s, %s" % (v(tc), v(u), v(tc)))
+                if half == 0:
+                    ops.append(("palloc", ps))
+                    ops.append(("palloc", pc))
+                I("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(ps[half]), v(hs), v(ts)))
+                I("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(pc[half]), v(hc), v(tc)))
+                if half == 1:
+                    for pair, quad in ((ps, kk), (pc, 12 + kk)):
+                        Q, r_ = divmod(quad, 8)
+                        byte = 64 * Q + 16 * (r_ % 4) + 8 * (r_ // 4)
+                        ops.append(("store", "buffer_store_dwordx2 v[%d:%d], %s, %%0, s%d offen offset:%d" % (pair[0], pair[1], v(vrow), S_GB + g, byte), pair))
+                    npack += 2
+        return ops
+
+    def emit_enc(self, op, early):
+        """one instruction of the encoder's stream into the tile body, with the books of vmcnt / lgkmcnt kept"""
+        if early:
+            for h in self.enc_held:
+                self.e(h[1])
+                self.vm_issue("store")
+            self.enc_held = []
+        kind = op[0]
+        if kind == "i":
+            self.e(op[1])
+        elif kind == "store":
+            if early:
+                self.e(op[1])
+                self.vm_issue("store")
+            else:
+                self.enc_held.append(op)
+        elif kind == "palloc":
+            assert all(h[2] != op[1] for h in self.enc_held), "a pack register pair is reused before its store was issued"
+        elif kind == "tneed":
+            self.vm_need(("t", op[1], 0))
+            self.vm_need(("t", op[1], 1))
+        elif kind == "sflush":
+            self.lg_flush()
+        elif kind == "sload":
+            self.e(op[1])
+        elif kind == "tload":
+            self.e(op[1])
+            self.vm_issue("x", op[2])
+        else:
+            raise KeyError(kind)
+
+    def enc_group_base(self, g, emit=None):
+        """s[S_GB + g] <- byte offset of group g's rows in the workgroup's scratch (the soffset of the unit's stores)"""
+        (emit or self.e)("s_add_u32 s%d, s%d, %d" % (S_GB + g, S_TB, g * 64 * ENC_ROW))
 
     def prefetch(self, nxt, g, line):
         """one 128-byte line of each feature row of group g (this / next tile) into the L2 / MALL: every lane touches one row; the loaded
@@ -472,7 +706,7 @@ class Gen:
         if lk == 4 and g == 0 and b < 12:        # xyz of group 0 for the skip layer (T idles through layers 1-4)
             c, q = divmod(b, 3)
             x((1, 0), treg(c, q), 0, 0, c, q, ("T", c, q))
-        if lk == 5 and g == 0 and b < 2:         # (lines of group 1's rows -> L2, see above)
+        if lk == 5 and g == 0 and b < 2 and not self.fused:         # (lines of group 1's rows -> L2, see above)
             ev.append(((1, 0), "pf", 0, 1, b))
         # xyz of group 1: fragment q of T is free once the LAST block of pass (5, g0) has issued its k-step 8 + q
         if lk == 5 and g == 0 and b == 15:
@@ -484,12 +718,18 @@ class Gen:
                 x((0, c), treg(c, 2), 0, 1, c, 2, ("T", c, 2))
         # the NEXT tile's layer-0 input of group 1 -> T: fragments 1, 2 are free from here on, fragment 0 carries group 0's view directions
         # through pass (9, g0)
-        if lk in (6, 7) and g == 0 and b % 4 == 0:
+        if lk in (6, 7) and g == 0 and b % 4 == 0 and not self.fused:
             j = (lk - 6) * 4 + b // 4
             c, q = j // 2, 1 + j % 2
             x((1, 0), treg(c, q), 1, 1, c, q, ("T", c, q))
-        if lk == 7 and g == 1 and b in (0, 8):   # (lines of the next tile's group-0 rows -> L2 / MALL; group 1's were touched above)
+        # (fused body: T[c][1..2] are the encoder's temporaries through layers 6 - 8; the rows it wrote are fetched in pass (9, g0))
+        if self.fused and lk == 9 and g == 0 and l == 9 and b < 8:
+            c, q = b // 2, 1 + b % 2
+            x((2, 0), treg(c, q), 1, 1, c, q, ("T", c, q))
+        if lk == 7 and g == 1 and b in (0, 8) and not self.fused:   # (lines of the next tile's group-0 rows -> L2 / MALL; group 1's were touched above)
             ev.append(((1, 0), "pf", 1, 0, b // 8))
+        if self.fused and lk == 5 and g == 1 and b in (2, 6):      # the encoder's inputs of the next tile's groups (ray row, fenceposts)
+            ev.append(((3, 0), "encfetch", (b - 2) // 4))
         if lk == 8 and g == 0 and b < 4:         # view directions of group 0 for layer 9
             x((1, 0), treg(b, 0), 0, 0, b, 3, ("T", b, 0))
         if lk == 9 and g == 0 and l == 9 and b < 4:   # view directions of group 1: fragment 4 of F0 (layer 9 writes fragments 0-3 only)
@@ -610,6 +850,23 @@ class Gen:
                     gaps[(0, 0)].append(("bases", nper & 1, rowb(K[nb["l"]]), nb["lds"] // SLOT_BYTES * SLOT_BYTES))
                 if any(x["l"] == 10 and x["period"] == blk["period"] for x in blocks):
                     gaps[(0, 0)].append(("base_h", rowb(K[10]), blk["lds"] // SLOT_BYTES * SLOT_BYTES))
+            # fused body: the encoder of the next tile's groups rides in the gaps of layers 6 - 8 (96 blocks: 48 per group)
+            in_period = [x for x in blocks if x["period"] == blk["period"]].index(blk)
+            enc_early = True
+            if self.fused and blk["lk"] in (6, 7, 8):
+                wdx = (blk["lk"] - 6) * 32 + g * 16 + b
+                ug, wi = divmod(wdx, 48)
+                if wi == 0:
+                    if ug == 0:
+                        gaps[(0, 0)].append(("encbase",))
+                    self.enc_stream = self.enc_unit_ops(ug)
+                ne = len(self.enc_stream)
+                mine = self.enc_stream[wi * ne // 48:(wi + 1) * ne // 48]
+                for t, op in enumerate(mine):
+                    gaps[divmod((t * nks * 4) // len(mine), 4)].append(("enc", op))
+                # (stores count into vmcnt: none in the second half of a period, where the wait for the period's weight chunk would sit
+                # behind them; the window's last period takes what is left)
+                enc_early = in_period < 2 or wdx >= 92
             # re-pack of the previous block: one instruction per gap (gaps 1-3 of the first kmax k-steps)
             ops = self.repack_ops(blocks[i - 1]) if i > 0 else []
             # (experiment, G2_DUMMY_VALU="v,t": v plain + t transcendental VALU instructions more per block on a register nothing reads --
@@ -666,6 +923,14 @@ class Gen:
                             self.set_bases(*it[1:])
                         elif it[0] == "base_h":
                             self.set_base_h(*it[1:])
+                        elif it[0] == "enc":
+                            self.emit_enc(it[1], enc_early)
+                        elif it[0] == "encfetch":
+                            for op in self.enc_fetch_ops(False, it[1]):
+                                self.emit_enc(op, True)
+                        elif it[0] == "encbase":
+                            self.enc_group_base(0)
+                            self.enc_group_base(1)
             if SKIP_FILL is not None and i % SKIP_EVERY == SKIP_EVERY - 1:
                 self.out.append("\ts_branch .Lskip%%=_%d" % i)
                 if SKIP_FILL:
@@ -675,6 +940,12 @@ class Gen:
                 serials = [self.last_piece[k] for k in due.get(blk["period"], []) if k in self.last_piece]
                 if serials:
                     self.vm_wait_serial(max(serials))
+                if self.fused and blk["lk"] == 8 and g == 1 and b == 15:
+                    # every row the encoder stored is in the L2 before pass 9 fetches the first of them (a store retires at any time
+                    # relative to the loads: only a full drain says so)
+                    assert not self.enc_held, "encoder stores left over at the end of the window"
+                    self.e("s_waitcnt vmcnt(0)")
+                    self.vm, self.pending = [], {}
                 if not NOBARRIER:
                     self.e("s_barrier")
                 state["period"] = blk["period"] + 1
@@ -708,7 +979,10 @@ class Gen:
         e("v_and_b32 v%d, 15, v%d" % (V_TMP1, V_TMP0))
         e("v_lshrrev_b32 v%d, 4, v%d" % (V_LG16, V_TMP0))
         e("v_lshlrev_b32 v%d, 4, v%d" % (V_LG16, V_LG16))
-        e("v_lshlrev_b32 v%d, 8, v%d" % (V_VX, V_TMP1))
+        if self.fused:
+            e("v_mul_u32_u24 v%d, %d, v%d" % (V_VX, ENC_ROW, V_TMP1))
+        else:
+            e("v_lshlrev_b32 v%d, 8, v%d" % (V_VX, V_TMP1))
         e("v_add_u32 v%d, v%d, v%d" % (V_VX, V_VX, V_LG16))
         e("v_mul_u32_u24 v%d, %d, v%d" % (V_VST, self.rs, V_TMP1))
         e("v_add_u32 v%d, 16, v%d" % (V_VST1, V_VST))
@@ -722,12 +996,24 @@ class Gen:
                     self.dma_setup(IMG_OFF[d["chunk"]] + c0 * 1024, d["slot"] * SLOT_BYTES + c0 * 1024, npw)
                     e("s_nop 0")
                 e("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d" % (V_LANE16, S_CUR, S_CUR + 1, (i - c0) * 1024))
+        if self.fused:      # the first tile's rows: both groups encoded here, nothing beside them
+            self.enc_group_base(0)
+            self.enc_group_base(1)
+            for g in (0, 1):
+                for op in self.enc_fetch_ops(True, g):
+                    e(op[1])
+            e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+            for g in (0, 1):
+                for op in self.enc_unit_ops(g):
+                    if op[0] in ("i", "store"):
+                        e(op[1])
+            e("s_waitcnt vmcnt(0)")
         for c in range(4):
             for q in range(3):
                 for (dst, g) in ((frag(1, c, 4 + q), 0), (treg(c, q), 1)):
-                    e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, (g * 64 + c * 16) * FEAT_ROW))
+                    e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, (g * 64 + c * 16) * (ENC_ROW if self.fused else FEAT_ROW)))
                     e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
-                    e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d%s" % (reg(dst[0], dst[1], 4), V_TMP1, 64 * q, XPOLICY))
+                    e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d%s" % (reg(dst[0], dst[1], 4), V_TMP1, 64 * q, " sc1" if self.fused else XPOLICY))
         e("s_waitcnt vmcnt(0)")
         e("s_barrier")
 
@@ -744,13 +1030,24 @@ class Gen:
             self.out.append("\t.fill %d, 4, 0xbf800000" % (HEAD_PAD // 4))
             self.out.append(".Lpad%=:")
         e("s_lshl_b32 s%d, %%5, 10" % S_SWAVE)
-        if XSAME:
+        if self.fused:
+            e("s_mul_i32 s%d, %%5, %d" % (S_TB, 128 * ENC_ROW))       # this wave's rows in the workgroup's scratch
+            e("s_lshl_b32 s%d, %%6, 3" % S_GC)                        # groups of 64 samples: tile * 8 + wave * 2 + g
+            e("s_lshl_b32 s%d, %%5, 1" % S_T0)
+            e("s_add_u32 s%d, s%d, s%d" % (S_GC, S_GC, S_T0))
+            e("s_lshl_b32 s%d, %%7, 3" % S_TBN)
+            e("s_add_u32 s%d, s%d, s%d" % (S_TBN, S_TBN, S_GC))       # (S_TBN: the next tile's first group)
+            e("s_mov_b32 s%d, %s" % (S_CT, lit(314.159271)))
+        elif XSAME:
             e("s_mov_b32 s%d, 0" % S_TB)
         else:
             e("s_lshl_b32 s%d, %%6, 17" % S_TB)           # tile * 512 rows * 256 bytes
-        e("s_lshl_b32 s%d, %%5, 15" % S_T0)           # wave * 128 rows
-        e("s_add_u32 s%d, s%d, s%d" % (S_TB, S_TB, S_T0))
-        if XSAME:
+        if not self.fused:
+            e("s_lshl_b32 s%d, %%5, 15" % S_T0)           # wave * 128 rows
+            e("s_add_u32 s%d, s%d, s%d" % (S_TB, S_TB, S_T0))
+        if self.fused:
+            pass
+        elif XSAME:
             e("s_mov_b32 s%d, s%d" % (S_TBN, S_TB))
         else:
             e("s_lshl_b32 s%d, %%7, 17" % S_TBN)
@@ -768,14 +1065,14 @@ class Gen:
         self.out.append(".Lsteady%=:")
 
 
-def generate(depth_head, stamp):
-    g1 = Gen(depth_head, stamp)
+def generate(depth_head, stamp, fused=False):
+    g1 = Gen(depth_head, stamp, fused=fused)
     g1.tile()                                                  # pass 1: what a tile leaves outstanding for the next one
     carry = dict(vm=g1.vm, serial=g1.vm_serial, pending=g1.pending, last_piece=g1.last_piece)
-    g2 = Gen(depth_head, stamp, carry)
+    g2 = Gen(depth_head, stamp, carry, fused=fused)
     g2.head()
     blocks, NK = g2.tile()
-    g3 = Gen(depth_head, stamp, dict(vm=g2.vm, serial=g2.vm_serial, pending=g2.pending, last_piece=g2.last_piece))   # (fixed point: pass 3 must repeat pass 2)
+    g3 = Gen(depth_head, stamp, dict(vm=g2.vm, serial=g2.vm_serial, pending=g2.pending, last_piece=g2.last_piece), fused=fused)   # (fixed point: pass 3 must repeat pass 2)
     g3.head()
     g3.tile()
     strip = lambda out: [x for x in out]
@@ -797,6 +1094,9 @@ def tables(blocks):
     t.append("#define G2_GENERATOR_OPTIONS \"%s\"" % options_string())
     regs = ['"v%d"' % i for i in range(256)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in sregs]
     t.append("#define G2_CLOBBERS %s, \"vcc\", \"scc\", \"memory\"" % ", ".join(regs))
+    regs = ['"v%d"' % i for i in range(256)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in list(range(S_GB, S_E3 + 1)) + list(S_CLOBBER)]
+    t.append("#define G2E_CLOBBERS %s, \"vcc\", \"scc\", \"memory\"" % ", ".join(regs))
+    t.append("#define G2E_ROW_BYTES %d" % ENC_ROW)
     return t
 
 
@@ -823,6 +1123,10 @@ if __name__ == "__main__":
                 with open(os.path.join(outdir, "mlp_f16_g2_body_d%d.gen.inc" % depth_head), "w") as f:
                     f.write(text.replace("v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16").replace("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32"))
             nlines = len(g.out)
+        # the fused body (encoder inside the kernel): bf16 rows (the fp16 tier's rows keep safe_sin's exact remainder: not generated)
+        g, blocks, NK = generate(depth_head, 0, fused=True)
+        with open(os.path.join(outdir, "mlp_bf16_g2e_body_d%d.gen.inc" % depth_head), "w") as f:
+            f.write("".join('"%s\\n"\n' % x for x in g.out))
     with open(os.path.join(outdir, "mlp_bf16_g2_tables.gen.inc"), "w") as f:
         f.write("\n".join(tables(blocks)) + "\n")
     total_pieces = sum(npw_of(d["chunk"]) for d in real)

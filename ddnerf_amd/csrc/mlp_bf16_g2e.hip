@@ -1,0 +1,147 @@
+// K1 + K2 (bf16) in ONE kernel: cast_rays + integrated_pos_enc + the view-direction columns + the 8x256 MLP -- the reference's
+// run_network (models/models.py:117-142: cast_rays, integrated_pos_enc, positional_encoding of the view directions, concat, the network)
+// is one step, and so it is here: the encoded feature rows [M,128] never exist in HBM.  The tile body is the two-group body of
+// mlp_bf16_g2.hip generated with its encoder switched on (gen_bf16_g2.py, Gen(fused=True): the design note is in its header): while
+// layers 6 - 8 of a tile run, the vector-ALU gaps of the MFMA stream encode the NEXT tile's samples (lane = sample: the Gaussian of the
+// sample's interval, then per octave and axis the damped sine / cosine on the hardware transcendentals) into 192-byte rows of a scratch
+// area private to the workgroup (96 KiB, rewritten every tile: it lives in the L2), from which the body fetches what the unfused body
+// fetches from the feature rows.  The view-direction k-step comes from a per-RAY table (27 values per ray, not per sample).
+// Outputs are bit-identical to ddnerf_encode(feat_dtype = 1) followed by ddnerf_mlp_bf16_forward (tests/test_hip_fused_mlp.py).
+// Compiled with -ffp-contract=off (the ray table repeats rays_encode.hip's arithmetic operation for operation).
+#include "mlp_bf16_common.h"
+
+#include "mlp_bf16_g2_tables.gen.inc"
+
+#define G2E_SLOT_BYTES (36 * 1024)
+#define G2E_LDS_BYTES (4 * G2E_SLOT_BYTES)
+#define G2E_TILE 512
+#define G2E_SCRATCH_PER_WG (G2E_TILE * G2E_ROW_BYTES)
+#define G2E_TABLE_FLOATS 32   // per ray: 16 floats (o, d, radius^2, d^2, 1 - d^2 / |d|^2, three unused), then 32 bf16 view-direction columns in k-order
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- the per-ray table -----------------------------------------------------------------------------------------------------------
+// general_utils/math_utils.py:34-54 (lift_gaussian: d^2, the null-space factor) and general_utils/nerf_helpers.py:127-171 (the view
+// directions' positional encoding), the values encode_kernel<1> computes per sample / per block (rays_encode.hip phase 1 and 1b).
+__global__ void g2e_ray_table_kernel(const float *__restrict__ rays, int n, float *__restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + 12 * (size_t)i;
+    float *t = table + G2E_TABLE_FLOATS * (size_t)i;
+    const float d0 = r[3], d1 = r[4], d2 = r[5];
+    const float q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+    const float dmag = fmaxf(1e-10f, (q0 + q1) + q2);
+    t[0] = r[0], t[1] = r[1], t[2] = r[2];
+    t[3] = d0, t[4] = d1, t[5] = d2;
+    t[6] = r[6] * r[6];
+    t[7] = q0, t[8] = q1, t[9] = q2;
+    t[10] = 1.0f - q0 / dmag, t[11] = 1.0f - q1 / dmag, t[12] = 1.0f - q2 / dmag;
+    t[13] = t[14] = t[15] = 0.0f;
+    float dirv[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) dirv[k] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = r[9 + a];
+        dirv[a] = v;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float x = v * (float)(1 << f);
+            dirv[3 + f * 6 + a] = __builtin_amdgcn_sinf(x * 0.15915494f);
+            dirv[3 + f * 6 + 3 + a] = __builtin_amdgcn_sinf((x + 1.57079637f) * 0.15915494f);
+        }
+    }
+    unsigned short *row = (unsigned short *)(t + 16);
+#pragma unroll
+    for (int p = 0; p < 32; ++p) row[p] = __builtin_bit_cast(unsigned short, (__bf16)dirv[korder32(p)]);
+}
+
+DDN_EXPORT size_t ddnerf_ray_table_bytes(int n) { return (size_t)(n > 0 ? n : 0) * G2E_TABLE_FLOATS * sizeof(float); }
+DDN_EXPORT int ddnerf_ray_table(const float *rays, int n, void *table, ddnerf_stream_t stream) {
+    DDN_REQUIRE(rays && table, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ddn_aligned(table, 128), DDNERF_E_ALIGN);
+    hipLaunchKernelGGL(g2e_ray_table_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, rays, n, (float *)table);
+    return ddn_launch_status();
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------------------------
+struct G2EArgs {
+    const float *t_vals;     // [n, S + 1]
+    const float *table;      // ddnerf_ray_table
+    const char *packed;      // the two-group kernel's weight image
+    float *raw;
+    char *scratch;           // G2E_SCRATCH_PER_WG bytes per workgroup
+    long M, ntiles;
+    unsigned n, s1, magic, d64;
+};
+
+template <bool DEPTH_HEAD>
+__global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[G2E_LDS_BYTES];
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    // raw buffers (stride 0, byte count, the raw-buffer format word): offsets past the end load zero / drop the store
+    const char *sc = a.scratch + (size_t)blockIdx.x * G2E_SCRATCH_PER_WG;
+    const u32x4 srs = {(unsigned)(size_t)sc, (unsigned)((size_t)sc >> 32) & 0xffffu, (unsigned)G2E_SCRATCH_PER_WG, 0x00020000u};
+    const u32x4 rrs = {(unsigned)(size_t)a.raw, (unsigned)((size_t)a.raw >> 32) & 0xffffu, (unsigned)(a.M * (DEPTH_HEAD ? 24 : 16)), 0x00020000u};
+    const u32x4 trs = {(unsigned)(size_t)a.t_vals, (unsigned)((size_t)a.t_vals >> 32) & 0xffffu, (unsigned)((size_t)a.n * a.s1 * 4), 0x00020000u};
+    const u32x4 yrs = {(unsigned)(size_t)a.table, (unsigned)((size_t)a.table >> 32) & 0xffffu, (unsigned)((size_t)a.n * (G2E_TABLE_FLOATS * 4)), 0x00020000u};
+    const unsigned plo = (unsigned)(size_t)a.packed, phi = (unsigned)((size_t)a.packed >> 32);
+    const unsigned grid = gridDim.x, tile0 = blockIdx.x;
+    const unsigned s1 = a.s1, magic = a.magic, nmax = a.n - 1, d64 = a.d64;
+    const unsigned long tab = (unsigned long)(size_t)a.table;
+#pragma clang loop unroll(disable)
+    for (unsigned tile = tile0; tile < (unsigned)a.ntiles; tile += grid) {
+        if constexpr (DEPTH_HEAD) {
+            asm volatile(
+#include "mlp_bf16_g2e_body_d1.gen.inc"
+                :
+                : "s"(srs), "s"(rrs), "s"(plo), "s"(phi), "s"(lds0), "s"(wave), "s"(tile), "s"(grid), "s"(tile0), "s"(trs), "s"(yrs), "s"(s1),
+                  "s"(magic), "s"(nmax), "s"(d64), "s"(tab)
+                : G2E_CLOBBERS);
+        } else {
+            asm volatile(
+#include "mlp_bf16_g2e_body_d0.gen.inc"
+                :
+                : "s"(srs), "s"(rrs), "s"(plo), "s"(phi), "s"(lds0), "s"(wave), "s"(tile), "s"(grid), "s"(tile0), "s"(trs), "s"(yrs), "s"(s1),
+                  "s"(magic), "s"(nmax), "s"(d64), "s"(tab)
+                : G2E_CLOBBERS);
+        }
+    }
+    // (the last tile issued the next one's chunks, rows and inputs: let them land before the wave ends)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// (32-bit byte offsets into t_vals and the outputs, the next tile's included)
+#define G2E_MAX_LAUNCH (1L << 22)
+
+// scratch the forward needs: one row area per workgroup of the persistent grid
+DDN_EXPORT size_t ddnerf_encode_mlp_bf16_scratch_bytes(void) { return (size_t)ddn_cu_count() * G2E_SCRATCH_PER_WG; }
+
+extern "C" size_t ddnerf_mlp_bf16g1_packed_bytes(int depth_head);
+
+// rays are given as their table (ddnerf_ray_table); t_vals [n, S + 1]; packed: the image of ddnerf_mlp_bf16_pack; raw [n * S, 4 | 6].
+// Cone rays only, S a multiple of 64 (a group of 64 samples lies on one ray), n * S <= 2^22: DDNERF_E_RANGE otherwise -- the caller
+// then runs ddnerf_encode + ddnerf_mlp_bf16_forward, which produce the same bits.
+DDN_EXPORT int ddnerf_encode_mlp_bf16_forward(const void *ray_table, const float *t_vals, const void *packed, int depth_head, float *raw,
+                                              int n, int S, void *scratch, ddnerf_stream_t stream) {
+    DDN_REQUIRE(ray_table && t_vals && packed && raw && scratch, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(S % 64 == 0 && (long)n * S <= G2E_MAX_LAUNCH, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(ray_table, 128) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16) && ddn_aligned(scratch, 16) && ddn_aligned(t_vals, 4),
+                DDNERF_E_ALIGN);
+    const long M = (long)n * S;
+    const long ntiles = (M + G2E_TILE - 1) / G2E_TILE;
+    const int n_cu = ddn_cu_count();
+    const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
+    const size_t img = (ddnerf_mlp_bf16g1_packed_bytes(depth_head) + 255) & ~(size_t)255;   // (the two-group kernel's image inside the common one)
+    const unsigned d64 = (unsigned)(S / 64);
+    G2EArgs a{t_vals, (const float *)ray_table, (const char *)packed + img, raw, (char *)scratch, M, ntiles, (unsigned)n, (unsigned)(S + 1),
+              (unsigned)(((1ull << 31) + d64 - 1) / d64), d64};
+    if (depth_head)
+        hipLaunchKernelGGL(mlp_bf16g2e_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(mlp_bf16g2e_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return ddn_launch_status();
+}

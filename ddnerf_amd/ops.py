@@ -149,6 +149,45 @@ def _bf16_variant_forward(which, feat, packed, depth_head):
     return raw
 
 
+def ray_table(rays):
+    """rays [n,12] -> the fused kernel's per-ray table [n,32] (fp32 words: 16 floats, then the ray's view-direction row as 32 bf16)"""
+    rays = _f32c(rays, "rays")
+    n = rays.shape[0]
+    table = torch.empty((n, 32), dtype=torch.float32, device=rays.device)
+    _lib.check(_lib.lib().ddnerf_ray_table(_ptr(rays), n, _ptr(table), _stream()), "ddnerf_ray_table")
+    return table
+
+
+_FUSED_SCRATCH = {}
+
+
+def encode_mlp_bf16_supported(S, M, cylinder=False):
+    return (not cylinder) and S % 64 == 0 and M <= (1 << 22)
+
+
+def encode_mlp_bf16_forward(table, t_vals, packed, depth_head):
+    """models/models.py:117-142 as one launch (bf16 tier): cast_rays + integrated_pos_enc + view directions + the MLP; t_vals [n,S+1]
+    -> raw [n*S, 4|6], bit for bit encode(kind="bf16") + mlp_bf16_forward"""
+    t_vals = _f32c(t_vals, "t_vals")
+    n, S = t_vals.shape[0], t_vals.shape[1] - 1
+    M = n * S
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=t_vals.device)
+    key = (t_vals.device.index, torch.cuda.current_stream().cuda_stream)
+    scratch = _FUSED_SCRATCH.get(key)
+    if scratch is None:     # (one area per device and stream: launches on one stream run one after the other)
+        scratch = _FUSED_SCRATCH[key] = torch.empty(_lib.lib().ddnerf_encode_mlp_bf16_scratch_bytes(), dtype=torch.uint8, device=t_vals.device)
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_encode_mlp_bf16_forward(_ptr(table), _ptr(t_vals), _ptr(packed), int(depth_head), _ptr(raw), n, S,
+                                                             _ptr(scratch), _stream()), "ddnerf_encode_mlp_bf16_forward")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw
+
+
 # The two kernels behind mlp_bf16_forward by name (it picks by launch size; they produce the same bits for the same sample):
 # "g1" a workgroup owns 256 samples (mlp_bf16.hip), "g2" 512 samples as two groups per wave (mlp_bf16_g2.hip); each has its own image.
 def mlp_bf16g1_pack(params_flat, depth_head):

@@ -116,6 +116,22 @@ size_t ddnerf_mlp_bf16g2_packed_bytes(int depth_head);
 int ddnerf_mlp_bf16g2_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, int depth_head, float *raw, long M, ddnerf_stream_t stream);
 
+/* a3 + a4 + a5 + a7 in ONE kernel (bf16 tier): run_network, models/models.py:117-142 -- cast_rays, integrated_pos_enc, the view directions'
+ * positional encoding, the concat and the network are one step there, and the encoded rows [n*S,128] never exist in memory here: the
+ * two-group kernel above carries the encoder in the vector-ALU gaps of its MFMA stream (gen_bf16_g2.py, Gen(fused=True)).
+ *   ddnerf_ray_table: rays [n,12] (ddnerf_pack_rays) -> one 128-byte row per RAY: origin, direction, radius^2, d^2, 1 - d^2/|d|^2 as
+ *     fp32 (general_utils/math_utils.py:34-54), then the ray's 32 view-direction columns (general_utils/nerf_helpers.py:127-171) as a
+ *     bf16 row in k-order; table: ddnerf_ray_table_bytes(n) bytes, 128-byte aligned.
+ *   ddnerf_encode_mlp_bf16_forward: t_vals [n,S+1] -> raw [n*S, 4|6]; packed = the image of ddnerf_mlp_bf16_pack; scratch =
+ *     ddnerf_encode_mlp_bf16_scratch_bytes() bytes the launch may overwrite (its workgroups' private row areas).  Cone rays, S a
+ *     multiple of 64, n*S <= 2^22: otherwise DDNERF_E_RANGE, and the caller runs ddnerf_encode(feat_dtype 1) + ddnerf_mlp_bf16_forward,
+ *     whose outputs these are BIT FOR BIT. */
+size_t ddnerf_ray_table_bytes(int n);
+int ddnerf_ray_table(const float *rays, int n, void *table, ddnerf_stream_t stream);
+size_t ddnerf_encode_mlp_bf16_scratch_bytes(void);
+int ddnerf_encode_mlp_bf16_forward(const void *ray_table, const float *t_vals, const void *packed, int depth_head, float *raw, int n, int S,
+                                   void *scratch, ddnerf_stream_t stream);
+
 /* fp16-MFMA variant: the two bf16 kernels above built on v_mfma_f32_16x16x32_f16 / v_cvt_pk_f16_f32 (same rate, same registers, same
  * images, same schedule); feat: fp16 [M,128] in the same k-order, as written by ddnerf_encode(feat_dtype=2).  fp16 keeps 11
  * significant bits against bf16's 8 (operand rounding 8x smaller); biases, accumulation and outputs are fp32 as above.  Same

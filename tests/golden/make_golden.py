@@ -704,7 +704,7 @@ def gen_train300():
     _gen_train(300, 50, 300, 10, ("DDNerfModel", "GeneralMipNerfModel"), "train300")
 
 
-def _gen_train(iters, delay, max_steps, every, model_types, tag):
+def _gen_train(iters, delay, max_steps, every, model_types, tag, nudge=None, keep=False):
     """Training parity (SURVEY.md 8d "PSNR vs ref (2)"): 300 iterations of the reference's loop (train_model.py:132-177: smoothing
     schedule, lr schedule, run_iter, loss assembly, backward, one Adam per network) on a procedural scene -- a fresh seeded batch of
     256 rays per iteration with analytic colour targets -- with perturb / noise off (no random tensors).  The learning-rate
@@ -723,6 +723,11 @@ def _gen_train(iters, delay, max_steps, every, model_types, tag):
         load_weights(model.coarse, dd, 11, 1.0)
         if dd:
             load_weights(model.fine, False, 12, 1.0)
+        if nudge == "ulp":       # reference-vs-itself drift (gen_drift1500): every initial weight moved ONE fp32 ulp away from zero
+            with torch.no_grad():
+                for net in ([model.coarse, model.fine] if dd else [model.coarse]):
+                    for p_ in net.parameters():
+                        p_.copy_(torch.nextafter(p_, p_ * 2))
         optims = [torch.optim.Adam(model.coarse.parameters(), lr=cfg.optimizer.lr)]
         if dd:
             optims.append(torch.optim.Adam(model.fine.parameters(), lr=cfg.optimizer.lr))
@@ -761,9 +766,88 @@ def _gen_train(iters, delay, max_steps, every, model_types, tag):
                 rec["dp"].append(float(dp))
                 rec["lr"].append(float(lr_new))
                 print(model_type, i, float(loss), [float(m) for m in mses], flush=True)
+        if keep:                 # gen_trained / gen_drift1500 use the curve (and the trained model) themselves
+            return model, cfg, {k: np.array(v) for k, v in rec.items()}
         save("%s_%s_%s" % (tag, "dd" if dd else "mip", kind),
              meta=np.array([n, nc, nf, iters, delay, float(cfg.dataset.near), float(cfg.dataset.far), steps]),
              it=np.array(rec["it"]), loss=np.array(rec["loss"]), mse=np.array(rec["mse"]), dp=np.array(rec["dp"]), lr=np.array(rec["lr"]))
+
+
+TRAINED_ITERS = 3000
+
+
+def gen_trained():
+    """Parity on TRAINED weights (train_model.py:132-177 produces them; every other fixture uses seeded-uniform ones): the reference's
+    loop of gen_train1500 carried on to TRAINED_ITERS iterations; its final coarse / fine state_dicts (trained_weights_dd_blender.npz),
+    the curve (its first 1500 iterations must reproduce train1500_dd_blender.npz -- asserted here), and the reference's
+    run_iter(validation) with those weights on 4096 blender rays and on 4096 NDC rays (config_ff.yml), every 61st ray's outputs kept,
+    plus -- blender -- the sampler boundary of that pass: the inputs the reference hands sample_pdf_with_mu_sigma and its bin indices
+    for all 4096 x 129 samples."""
+    model, cfg_t, rec = _gen_train(TRAINED_ITERS, 2500, None, 25, ("DDNerfModel",), "train%d" % TRAINED_ITERS, keep=True)
+    old = np.load(os.path.join(HERE, "train1500_dd_blender.npz"))
+    k = len(old["it"]) - 1         # (the last record of the 1500-step run is iteration 1499, off the 25-grid)
+    assert np.array_equal(rec["it"][:k], old["it"][:k]) and np.array_equal(rec["loss"][:k], old["loss"][:k]), "train1500 not reproduced"
+    sd = {"c." + k_: v for k_, v in model.coarse.state_dict().items()}
+    sd.update({"f." + k_: v for k_, v in model.fine.state_dict().items()})
+    save("trained_weights_dd_blender", meta=np.array([TRAINED_ITERS, float(model.cfg.train_params.gaussian_smooth_factor)]),
+         it=rec["it"], loss=rec["loss"], mse=rec["mse"], dp=rec["dp"], **sd)
+    n, nc, nf = 4096, 64, 128
+    for kind in ("blender", "llff"):
+        cfg = load_cfg(CFG_OF[kind], nc, nf, kind)
+        for mode in ("train", "validation"):
+            cfg.nerf[mode]["radiance_field_noise_std"] = 0.0
+        if cfg.train_params.set_automatic_dist_reg_coeficient:
+            cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+        m2 = ref_models.DDNerfModel(cfg)
+        m2.coarse.load_state_dict(model.coarse.state_dict())
+        m2.fine.load_state_dict(model.fine.state_dict())
+        ro, rd, rad, tgt = synthetic.make_rays(kind, n, seed=1)
+        if kind == "blender":
+            tgt = synthetic.procedural_targets(ro, rd)
+        m2.eval()
+        with Spy() as spy:
+            with torch.no_grad():
+                (out, ind) = capture_gather_index(m2.run_iter, T(ro), T(rd), T(rad), mode="validation", rgb_target=T(tgt))
+        stride = 61
+        keep_ = {}
+        for lvl in out:
+            for k_ in ("rgb", "depth", "acc", "disp", "weights"):
+                keep_["o%d_%s" % (lvl, k_)] = out[lvl][k_][::stride]
+            for k_ in ("dp_loss", "mus_reg", "sig_reg", "mus_loss", "sig_loss"):
+                if out[lvl].get(k_, None) is not None:
+                    keep_["o%d_%s" % (lvl, k_)] = out[lvl][k_]
+        psnr = [float(-10 * torch.log10(torch.nn.functional.mse_loss(out[j]["rgb"], T(tgt)))) for j in range(2)]
+        print("trained", kind, "psnr vs target", psnr, flush=True)
+        save("fullsize_trained_dd_%s_%d_%dx%d" % (kind, n, nc, nf),
+             meta=np.array([n, nc, nf, 1.0, stride, float(cfg.dataset.near), float(cfg.dataset.far),
+                            float(cfg.train_params.dist_reg_coeficient), float(cfg.train_params.gaussian_smooth_factor),
+                            int(cfg.train_params.pdf_padding)]), psnr=np.array(psnr), **keep_)
+        if kind == "blender":
+            r = spy.rec
+            assert ind is not None and tuple(ind.shape) == (n, nf + 1) and int(ind.max()) < 256
+            save("sampler4096_trained", bins_row=r["s_bins"][0], weights=r["s_weights"], mus=r["s_mus"], ssig=r["s_ssig"],
+                 spart=r["s_spart"], sleft=r["s_sleft"], bins_ind=ind.to(torch.uint8), samples=r["s_out"],
+                 meta=np.array([n, nc, nf + 1, float(cfg.dataset.near), float(cfg.dataset.far), int(cfg.train_params.pdf_padding)], np.float64))
+
+
+def gen_drift1500():
+    """How far does the REFERENCE drift from ITSELF over the 1500 iterations of gen_train1500 under a perturbation of fp32 round-off
+    size?  (Unperturbed it reproduces train1500_dd_blender.npz bit for bit.)  Two nudges: every initial weight moved one ulp away from
+    zero ("ulp"), and the same arithmetic on 4 ATen threads instead of 8 ("thr4": other reduction splits).  The curves calibrate the
+    bars of tests/test_hip_baseline_size.py::test_training_curve_1500_iterations_of_the_real_schedule."""
+    old = np.load(os.path.join(HERE, "train1500_dd_blender.npz"))
+    out = {}
+    for tag in ("ulp", "thr4"):
+        torch.set_num_threads(4 if tag == "thr4" else 8)
+        _, _, rec = _gen_train(1500, 2500, None, 25, ("DDNerfModel",), "drift", nudge="ulp" if tag == "ulp" else None, keep=True)
+        torch.set_num_threads(8)
+        assert np.array_equal(rec["it"], old["it"])
+        out["loss_" + tag], out["mse_" + tag], out["dp_" + tag] = rec["loss"], rec["mse"], rec["dp"]
+        ps = lambda m: -10 * np.log10(m)  # noqa: E731
+        d = np.abs(ps(rec["mse"]) - ps(old["mse"]))
+        print("drift", tag, "max |dPSNR|", d.max(axis=0), "at", d.argmax(axis=0), "mean", d.mean(axis=0),
+              "max rel loss", np.max(np.abs(rec["loss"] - old["loss"]) / np.abs(old["loss"])), flush=True)
+    save("train1500_drift_dd_blender", it=old["it"], **out)
 
 
 def gen_ndcswitch():

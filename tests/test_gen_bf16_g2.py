@@ -25,8 +25,10 @@ def gen():
     return m
 
 
-@pytest.fixture(scope="module", params=[(0, 0), (1, 0), (0, 1)], ids=["rgb", "depth_head", "stamped"])
+@pytest.fixture(scope="module", params=[(0, 0, False), (1, 0, False), (0, 1, False), (0, 0, True), (1, 0, True)],
+                ids=["rgb", "depth_head", "stamped", "fused_rgb", "fused_depth_head"])
 def body(gen, request):
+    """(depth head, stamped, fused: the body with the encoder inside, mlp_bf16_g2e.hip)"""
     gen.STAMP_PERIODS = bool(request.param[1])       # (the per-period stamps of the diagnostic build: opt-in in the generator)
     g, blocks, nk = gen.generate(*request.param)     # (asserts that the counters' steady state is a fixed point)
     gen.STAMP_PERIODS = False
@@ -53,7 +55,7 @@ def test_plan(gen):
 
 
 def test_operand_ranges_and_counts(gen, body):
-    lines, (depth_head, stamp) = body
+    lines, (depth_head, stamp, fused) = body
     n_mfma = n_dma = 0
     for t in lines:
         op = t.split()[0]
@@ -82,8 +84,25 @@ def test_operand_ranges_and_counts(gen, body):
     pro = sum(gen.npw_of(d["chunk"]) for d in gen.real if d["for_next_tile"])
     assert n_dma == 389 + pro                                                # the steady state + the first tile's prologue
     assert sum(1 for t in lines if t == "s_barrier") == gen.NPER + 1
-    n_store = sum(1 for t in lines if t.startswith("buffer_store"))
-    assert n_store == (16 if depth_head else 8)
+    n_store = sum(1 for t in lines if t.startswith("buffer_store") and "%1," in t)
+    assert n_store == (16 if depth_head else 8)                              # the outputs
+    assert sum(1 for t in lines if t.startswith("buffer_store")) == n_store + (96 if fused else 0)
+    if fused:
+        enc = [t for t in lines if t.startswith("buffer_store_dwordx2") and "%0" in t]
+        # the encoder: 2 groups x 24 four-column pieces per tile, and the same once more in the first tile's prologue; every piece of a
+        # 192-byte row exactly once per group
+        assert len(enc) == 96
+        start = lines.index(".Lsteady%=:") + 1
+        for part in (lines[:start], lines[start:]):
+            offs = {}
+            for t in part:
+                if t.startswith("buffer_store_dwordx2") and "%0" in t:
+                    soff = t.split(",")[3].split()[0]
+                    m = re.search(r"offset:(\d+)", t)
+                    offs.setdefault(soff, []).append(int(m.group(1)) if m else 0)
+            assert sorted(offs) == ["s46", "s47"] and all(sorted(v) == list(range(0, 192, 8)) for v in offs.values())
+        assert sum(1 for t in lines if t.startswith("v_sin_f32")) == 4 * 96 and sum(1 for t in lines if t.startswith("v_exp_f32")) == 4 * 48
+        assert sum(1 for t in lines if t.startswith("v_div_fmas_f32")) == 4 * 4
 
 
 def test_memory_counter_replay(gen, body):
@@ -94,7 +113,7 @@ def test_memory_counter_replay(gen, body):
     lines, _ = body
     start = lines.index(".Lsteady%=:") + 1
     steady = lines[start:]
-    vm, lg = [], []          # in-flight loads: lists of (destination registers)
+    vm, lg, sm = [], [], []  # in-flight loads: lists of (destination registers)
     for rep in range(3):
         for t in steady:
             op = t.split()[0]
@@ -108,6 +127,8 @@ def test_memory_counter_replay(gen, body):
                 if m:
                     n = int(m.group(1))
                     lg = lg[len(lg) - n:] if n else []
+                    if not n:
+                        sm = []             # (scalar memory returns out of order: only lgkmcnt(0) says that a scalar load has landed)
                 continue
             args = toks.split(None, 1)[1] if " " in toks else ""
             parts = [p.strip() for p in args.split(",")]
@@ -123,6 +144,9 @@ def test_memory_counter_replay(gen, body):
             elif op == "s_memtime":
                 lg.append(set(_regs(parts[0])))
                 reads = []
+            elif op.startswith("s_load"):
+                sm.append(set(_regs(parts[0])))
+                reads = _regs(parts[2]) if len(parts) > 2 else []
             elif op.startswith(("buffer_store", "global_store")):
                 reads = _regs(parts[0]) + _regs(parts[1])
             elif op.startswith(("v_", "s_")) and parts and op not in ("s_barrier", "s_nop", "s_cbranch_scc1"):
@@ -132,11 +156,11 @@ def test_memory_counter_replay(gen, body):
             else:
                 reads = []
             inflight = set().union(*vm) if vm else set()
-            inflight_l = set().union(*lg) if lg else set()
+            inflight_l = set().union(*(lg + sm)) if lg or sm else set()
             for r in reads:
                 assert r not in inflight, ("read of a register a load is still filling", t)
                 assert r not in inflight_l, ("read of a register an LDS read is still filling", t)
-        assert not lg                                       # (the body ends with lgkmcnt(0))
+        assert not lg and not sm                            # (the body ends with lgkmcnt(0))
     assert len(vm) < 64
 
 

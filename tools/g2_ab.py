@@ -16,7 +16,7 @@ import g2_clock  # noqa: E402
 def main():
     M = 524288
     runs = []
-    for so in sys.argv[1:]:
+    for so in [a for a in sys.argv[1:] if not a.startswith("--")]:
         torch.manual_seed(0)                      # (every library gets the same feature rows)
         L, launch, keep = g2_clock.setup(so, M)
         runs.append((os.path.basename(so), launch, keep))
@@ -25,8 +25,10 @@ def main():
         launch()
         torch.cuda.synchronize()
         outs.append(keep[2].clone())
+    differ = False
     for (name, _, _), o in zip(runs[1:], outs[1:]):
         print("%s: outputs %s the first library's (max |diff| %.3g)" % (name, "EQUAL" if torch.equal(o, outs[0]) else "DIFFER from", float((o - outs[0]).abs().max())))
+        differ |= not torch.equal(o, outs[0])
     t0 = time.time()
     while time.time() - t0 < 2.0:
         for _, launch, _ in runs:
@@ -46,6 +48,8 @@ def main():
     for name, ts in times.items():
         med = statistics.median(ts)
         print("%-28s median %.4f ms  min %.4f  frac(median) %.4f" % (name, med, min(ts), 1220608 * M / med / 1e9 / 2500))
+    if differ and "--allow-differ" not in sys.argv:      # (timing-only experiment bodies are SUPPOSED to differ: say so on the command line)
+        sys.exit("g2_ab: a library's outputs differ from the first library's")
 
 
 if __name__ == "__main__":
