@@ -64,13 +64,25 @@ DEPTH = 4        # A fragments are read this many k-steps ahead
 #   xsame=1           TIMING ONLY, results wrong: every tile fetches tile 0's feature rows (the fetches stay, their footprint goes)
 #   touchglc=1        the code-page touches bypass the scalar cache (glc)
 #   xpolicy=a_b       cache-policy bits of the feature fetches instead of `nt` (underscores for spaces; `none` = default policy)
-EXP_DEFAULT = dict(stamp_periods="0", stamp_ksteps="", sgpr_stamps="", dummy_valu="0,0", skip_fill="", skip_every="1", head_pad="0", align="0",
+#   enc_drain=1       (fused body) a full vmcnt drain between the encoder's last store and pass 9's first fetch of a stored row; the product relies on the
+#                     memory pipeline keeping a wave's store and its later load of the same address in order
+#   enc_store=0 / enc_valu=0 / enc_prologue=0   (fused body) TIMING ONLY, results wrong: the encoder's stores / its arithmetic / the first
+#                     tile's straight-line encoder are not issued
+#   enc_packed=1      (fused body) the column loop on the packed fp32 instructions (two columns per instruction; measured SLOWER: a
+#                     v_pk_*_f32 holds the vector ALU about four times as long as the scalar instruction)
+#   vm_inorder=0 / 1  stores are booked into the in-order queue of vmcnt like loads (a wait then allows the younger stores outstanding
+#                     too) or not (every wait is then for "no younger LOAD outstanding": stricter than necessary while a store is in
+#                     flight).  gfx9-family parts retire vector-memory loads AND stores of a wave in issue order (hipcc's own wait
+#                     insertion books both as one event type on parts without a separate store counter); auto = 1 in the fused body
+#                     (48 encoder stores per tile; measured 0.9 % of the launch), 0 in the unfused one (stores at the tile end only)
+EXP_DEFAULT = dict(enc_packed="0", vm_inorder="auto", enc_drain="0", enc_store="1", enc_valu="1", enc_prologue="1", stamp_periods="0", stamp_ksteps="", sgpr_stamps="", dummy_valu="0,0", skip_fill="", skip_every="1", head_pad="0", align="0",
                    dma_span="1/1", touch="", nodma="0", nox="0", pf="0", xpolicy="nt", pfpolicy="none", xsame="0", touchglc="0", nobarrier="0", kmax="7")
 EXP = dict(EXP_DEFAULT)
 
 
 def set_experiment(opts):
     """install experiment switches (dict key -> string); unknown keys are an error"""
+    global ENC_DRAIN, ENC_STORE, ENC_VALU, ENC_PROLOGUE, ENC_PACKED, VM_INORDER
     global STAMP_PERIODS, DUMMY_VALU, SKIP_FILL, SKIP_EVERY, HEAD_PAD, ALIGN, STAMP_KSTEPS, DMA_SPAN_NUM, DMA_SPAN_DEN, SGPR_STAMPS, TOUCH, NODMA, NOX, NOPF, XPOLICY, PFPOLICY, XSAME, TOUCHGLC, NOBARRIER, KMAX
     for k in opts:
         if k not in EXP_DEFAULT:
@@ -79,6 +91,8 @@ def set_experiment(opts):
     EXP.update(EXP_DEFAULT)
     EXP.update(opts)
     STAMP_PERIODS = EXP["stamp_periods"] == "1"
+    ENC_DRAIN, ENC_STORE, ENC_VALU, ENC_PROLOGUE = (EXP[k] == "1" for k in ("enc_drain", "enc_store", "enc_valu", "enc_prologue"))
+    ENC_PACKED, VM_INORDER = EXP["enc_packed"] == "1", EXP["vm_inorder"]
     DUMMY_VALU = [int(x) for x in EXP["dummy_valu"].split(",")]
     SKIP_FILL = int(EXP["skip_fill"]) if EXP["skip_fill"] != "" else None
     SKIP_EVERY = int(EXP["skip_every"])
@@ -116,19 +130,26 @@ TILE = 512
 # d^2, 1 - d^2/|d|^2 as fp32, then the ray's 32 view-direction columns as one k-order 16-bit row), S a multiple of 64 so that a group
 # of 64 samples (one sample per lane) lies on one ray.  While layers 6 - 8 run -- T[c][1..2], 32 registers, are idle there -- the VALU
 # gaps of the MFMA stream encode the NEXT tile's two groups, lane = sample: the Gaussian of the sample's interval (the arithmetic of
-# rays_encode.hip's gaussian_of_interval / encode_kernel<1>, operation for operation: IEEE divisions, no contraction), then per (octave,
-# axis) the damping 2^(-0.5 cov 4^d log2 e) and the sine and cosine on the hardware transcendentals, 16-bit pairs, and every four
-# columns one 8-byte store into the workgroup's private scratch rows (512 rows x 192 B, written and re-read every tile: L2-resident).
+# rays_encode.hip's gaussian_of_interval / encode_kernel<1>, operation for operation: IEEE divisions, no contraction), then two columns
+# at a time on the PACKED fp32 instructions (v_pk_mul / v_pk_fma / v_pk_add_f32: each half rounds like the scalar instruction) the
+# damping 2^(-0.5 cov 4^d log2 e) and the sine and cosine on the hardware transcendentals -- the scaled means / covariances of a column
+# pair live in a register pair that is multiplied by 4 / 16 from one pair of octaves to the next (exact) --, 16-bit pairs, and every
+# four columns one 8-byte store into the workgroup's private scratch (96 KiB, written and re-read every tile: L2-resident), laid out
+# [piece of four columns][sample] so that a store and the fetches are contiguous runs.
 # Everything that used to fetch a feature row fetches a scratch row instead -- the next tile's layer-0 inputs during pass 9, the skip
 # layer's xyz columns at layers 4 / 5 --; the view-direction k-step comes from the ray table.  Bit-identical to encode_kernel<1>
 # followed by the unfused body (tests/test_hip_fused_mlp.py).
-ENC_ROW = 192
+ENC_ROW = 192                                                        # bytes of one encoded sample
+ENC_GROUP = 64 * ENC_ROW                                             # a group's area: [24 four-column pieces][64 samples][8 bytes]
 V_EP = [128 + 12 * c + 4 + i for c in range(4) for i in range(8)]    # the encoder's 32 temporaries: T[c][1..2]
 V_ET = {0: (254, 255), 1: (247, 253)}                                # fenceposts t0, t1 of the next tile's groups (fetched in pass (5, g1))
-S_RAY = {0: 48, 1: 64}                                               # s[48:63], s[64:79]: the ray-table rows of the next tile's groups
+S_RAY = 48                                                           # s[48:63]: the ray-table row of the group being encoded
+# equal-halved constant pairs of the packed fp32 instructions (s_mov'ed by the head of every tile)
+S_C1, S_CT2, S_C2, S_HP, S_4, S_16 = 64, 66, 68, 70, 72, 74
 S_E0, S_E1, S_E2, S_E3 = 80, 81, 82, 83
 S_GB = 46                                                            # s46, s47: scratch byte offsets of this wave's two groups
-S_CT, S_GC = 92, 93                                                  # 100 pi (safe_sin's period); group index of this tile's first group
+S_ST = 76                                                            # soffset of the encoder's store being issued
+S_GC = 93                                                            # group index of this tile's first group
 # asm operands of the fused body: %0 scratch rows of this workgroup (buffer resource)  %1 outputs  %2 %3 weight image  %4 LDS base  %5 wave
 #   %6 tile  %7 grid  %8 first tile  %9 t_vals (buffer resource)  %10 ray table (buffer resource)  %11 S + 1  %12 ceil(2^31 / (S / 64))
 #   %13 n - 1  %14 S / 64  %15 ray table (64-bit address)
@@ -304,7 +325,7 @@ class Gen:
     # when no store is in flight and stricter than necessary when one is.
     def vm_issue(self, kind, key=None):
         self.vm_serial += 1
-        if kind != "store":
+        if kind != "store" or VM_INORDER == "1" or (VM_INORDER == "auto" and self.fused):
             self.vm.append((self.vm_serial, kind))
         if key is not None:
             self.pending[key] = self.vm_serial
@@ -360,9 +381,12 @@ class Gen:
         if self.fused:      # (the workgroup's scratch rows: one buffer, this tile's or the next one's according to WHEN the fetch runs)
             if q == 3:
                 return self.dir_load(dst, g, key)
-            self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, (g * 64 + c * 16) * ENC_ROW))
+            # positions 8 lg .. 8 lg + 7 of 32-column group q = the four-column pieces 8 q + lg and 8 q + 4 + lg of sample 16 c + s
+            self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, g * ENC_GROUP + 8 * q * 512 + c * 128))
             self.e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
-            self.e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d sc1" % (reg(kind, r, 4), V_TMP1, 64 * q))
+            self.e("buffer_load_dwordx2 %s, v%d, %%0, 0 offen sc1" % (reg(kind, r, 2), V_TMP1))
+            self.vm_issue("x")
+            self.e("buffer_load_dwordx2 %s, v%d, %%0, 0 offen offset:2048 sc1" % (reg(kind, r + 2, 2), V_TMP1))
             self.vm_issue("x", key)
             return
         self.e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TBN if nxt else S_TB, (g * 64 + c * 16) * FEAT_ROW))
@@ -388,41 +412,53 @@ class Gen:
         self.vm_issue("x", key)
 
     # ---- the encoder of the fused body
-    def enc_fetch_ops(self, cur, g, tregs=None):
-        """what a group's encoder reads: its ray's table row -> s[S_RAY[g]..+15], its samples' fenceposts -> tregs (lane = sample)"""
-        t0, t1 = tregs or V_ET[g]
+    def enc_fetch_ops(self, cur, g, what="rt"):
+        """what a group's encoder reads: "r" its ray's table row -> s[S_RAY..+15], "t" its samples' fenceposts -> V_ET[g] (lane = sample)"""
+        t0, t1 = V_ET[g]
         ops = []
         add = lambda s_: ops.append(("i", s_))
         self.ray_of_group(S_E1, cur, g, add)
-        add("s_add_u32 s%d, s%d, %d" % (S_E0, S_GC if cur else S_TBN, g))
-        add("s_mul_i32 s%d, s%d, %%14" % (S_E2, S_E1))
-        add("s_sub_u32 s%d, s%d, s%d" % (S_E2, S_E0, S_E2))
-        add("s_lshl_b32 s%d, s%d, 6" % (S_E2, S_E2))                       # first sample of the group on its ray
-        add("s_mul_i32 s%d, s%d, %%11" % (S_E3, S_E1))
-        add("s_add_u32 s%d, s%d, s%d" % (S_E3, S_E3, S_E2))
-        add("s_lshl_b32 s%d, s%d, 2" % (S_E3, S_E3))                       # byte offset of t_vals[ray][j0] (past the end: reads as zero)
-        add("s_min_u32 s%d, s%d, %%13" % (S_E1, S_E1))
-        add("s_lshl_b32 s%d, s%d, 7" % (S_E1, S_E1))
-        ops.append(("sload", "s_load_dwordx16 s[%d:%d], %%15, s%d" % (S_RAY[g], S_RAY[g] + 15, S_E1)))
-        add("v_lshrrev_b32 v%d, 2, v%d" % (V_TMP1, V_LANE16))
-        ops.append(("tload", "buffer_load_dword v%d, v%d, %%9, s%d offen" % (t0, V_TMP1, S_E3), ("t", g, 0)))
-        ops.append(("tload", "buffer_load_dword v%d, v%d, %%9, s%d offen offset:4" % (t1, V_TMP1, S_E3), ("t", g, 1)))
+        if "t" in what:
+            add("s_add_u32 s%d, s%d, %d" % (S_E0, S_GC if cur else S_TBN, g))
+            add("s_mul_i32 s%d, s%d, %%14" % (S_E2, S_E1))
+            add("s_sub_u32 s%d, s%d, s%d" % (S_E2, S_E0, S_E2))
+            add("s_lshl_b32 s%d, s%d, 6" % (S_E2, S_E2))                       # first sample of the group on its ray
+            add("s_mul_i32 s%d, s%d, %%11" % (S_E3, S_E1))
+            add("s_add_u32 s%d, s%d, s%d" % (S_E3, S_E3, S_E2))
+            add("s_lshl_b32 s%d, s%d, 2" % (S_E3, S_E3))                       # byte offset of t_vals[ray][j0] (past the end: reads as zero)
+            add("v_lshrrev_b32 v%d, 2, v%d" % (V_TMP1, V_LANE16))
+            ops.append(("tload", "buffer_load_dword v%d, v%d, %%9, s%d offen" % (t0, V_TMP1, S_E3), ("t", g, 0)))
+            ops.append(("tload", "buffer_load_dword v%d, v%d, %%9, s%d offen offset:4" % (t1, V_TMP1, S_E3), ("t", g, 1)))
+        if "r" in what:
+            add("s_min_u32 s%d, s%d, %%13" % (S_E1, S_E1))
+            add("s_lshl_b32 s%d, s%d, 7" % (S_E1, S_E1))
+            ops.append(("sload", "s_load_dwordx16 s[%d:%d], %%15, s%d" % (S_RAY, S_RAY + 15, S_E1)))
         return ops
 
-    def enc_unit_ops(self, g, tregs=None):
+    def enc_unit_ops(self, g, cur=False):
         """the encoder of one group of 64 samples (lane = sample) as a list of single instructions: ("i", text) plain, ("tneed", g)
-        wait for the fenceposts, ("sflush",) wait for the ray row, ("store", text, pair) an 8-byte store of four columns.
+        wait for the fenceposts, ("sflush",) wait for the ray row, ("store", text, pair) an 8-byte store of four columns, and -- in the
+        stream of group 0, once its ray row has been consumed -- the fetch of group 1's row into the same scalar registers.
         Arithmetic: rays_encode.hip gaussian_of_interval (cone) and encode_kernel<1> phase 2, operation for operation."""
-        t0, t1 = tregs or V_ET[g]
-        R = S_RAY[g]
+        t0, t1 = V_ET[g]
+        R = S_RAY
         P = list(V_EP)
         ops = []
         I = lambda s_: ops.append(("i", s_))
         v = lambda r: "v%d" % r
-        mean, cov = P[0:3], P[3:6]
-        vrow = P[6]
-        w = P[7:20]            # the Gaussian's temporaries; the value chain reuses them
-        packs = [(P[20 + 2 * i], P[21 + 2 * i]) for i in range(6)]
+        v2 = lambda r: "v[%d:%d]" % (r, r + 1)
+        s2 = lambda r: "s[%d:%d]" % (r, r + 1)
+        RR = [P[0], P[2], P[4]]          # scaled means of the three column pairs of an octave pair (register pairs)
+        QQ = [P[6], P[8], P[10]]         # their scaled covariances times -0.5 log2 e
+        U, F, YC, A = P[12], P[14], P[16], P[18]
+        packs = [(P[20], P[22]), (P[24], P[26])]       # (sine piece, cosine piece) of a four-column step, two steps in flight
+        vrow = P[28]
+        spare = P[29:32]
+        for x in RR + QQ + [U, F, YC, A] + [q for pr in packs for q in pr]:
+            assert x % 2 == 0
+        # the Gaussian's temporaries (all dead before the column loop starts)
+        w = [U, U + 1, F, F + 1, YC, YC + 1, A, A + 1, P[20], P[21], P[22], P[23], P[24]]
+        cov = [P[25], P[26], P[27]]
 
         def div(q, a, b, tmp):
             """q = a / b, correctly rounded (the sequence the compiler emits for an fp32 division with denormals on); tmp: 4 registers"""
@@ -441,9 +477,9 @@ class Gen:
 
         mu, hw, mu2, hw2, hw4, den, a_, q1, three = w[0:9]
         tmp = w[9:13]
-        tm, tv, rv = mean[0], mean[1], mean[2]        # (t_mean, t_var, r_var live in the mean registers until mean / cov are formed)
+        tm, tv, rv = spare                            # t_mean, t_var, r_var
         ops.append(("tneed", g))
-        I("v_mul_u32_u24 %s, 12, v%d" % (v(vrow), V_LANE16))                         # lane * 192: the sample's scratch row
+        I("v_lshrrev_b32 %s, 1, v%d" % (v(vrow), V_LANE16))                          # lane * 8: the sample's slot inside a piece
         I("v_add_f32 %s, %s, %s" % (v(mu), v(t0), v(t1)))
         I("v_sub_f32 %s, %s, %s" % (v(hw), v(t1), v(t0)))
         I("v_mul_f32 %s, 0.5, %s" % (v(mu), v(mu)))                                  # (t0 + t1) / 2
@@ -466,7 +502,7 @@ class Gen:
         div(mu, a_, three, tmp)                                                      # (mu is dead: mu^2 carries on)
         I("v_mul_f32 %s, %s, %s" % (v(mu), lit(0.266666681), v(mu)))
         I("v_sub_f32 %s, %s, %s" % (v(tv), v(q1), v(mu)))                            # t_var
-        I("v_mul_f32 %s, %s, %s" % (v(a_), lit(0.25), v(mu2)))                                # mu^2 / 4
+        I("v_mul_f32 %s, %s, %s" % (v(a_), lit(0.25), v(mu2)))                       # mu^2 / 4
         I("v_mul_f32 %s, %s, %s" % (v(q1), lit(0.416666657), v(hw2)))
         I("v_add_f32 %s, %s, %s" % (v(a_), v(a_), v(q1)))
         I("v_mul_f32 %s, %s, %s" % (v(q1), lit(0.266666681), v(hw4)))
@@ -482,66 +518,132 @@ class Gen:
             I("v_add_f32 %s, %s, %s" % (v(cov[a]), v(cov[a]), v(w[a])))
         for a in range(3):
             I("v_mul_f32 %s, s%d, %s" % (v(w[a]), R + 3 + a, v(tm)))
+        # the column pairs of octaves (0, 1): (x, y) | (z, x') | (y', z'), ' = the second octave: means into RR, -0.5 log2 e cov into QQ
+        m_dst = [RR[0], RR[0] + 1, RR[1]]
         for a in range(3):
-            I("v_add_f32 %s, s%d, %s" % (v(mean[a]), R + a, v(w[a])))
-        # the 48 (octave, axis) pairs in column order: column 3 d + a (sine), 48 + 3 d + a (cosine)
-        y, u, ts, tc, yc, hs, hc = w[0:7]
-        npack = 0
-        for col in range(48):
-            d, a = divmod(col, 3)
-            if d == 0:
-                ysrc = v(mean[a])
-            else:
-                I("v_mul_f32 %s, %s, %s" % (v(y), lit(float(1 << d)), v(mean[a])))
-                ysrc = v(y)
-            I("v_mul_f32 %s, %s, %s" % (v(u), lit(-0.5 * float(4 ** d) * f32(1.44269502)), v(cov[a])))
-            I("v_exp_f32 %s, %s" % (v(u), v(u)))
-            I("v_mul_f32 %s, %s, %s" % (v(ts), lit(0.0031830988), ysrc))
-            I("v_add_f32 %s, %s, %s" % (v(yc), lit(1.57079637), ysrc))
-            I("v_floor_f32 %s, %s" % (v(ts), v(ts)))
-            I("v_mul_f32 %s, %s, %s" % (v(tc), lit(0.0031830988), v(yc)))
-            I("v_fma_f32 %s, -%s, s%d, %s" % (v(ts), v(ts), S_CT, ysrc))
-            I("v_floor_f32 %s, %s" % (v(tc), v(tc)))
-            I("v_mul_f32 %s, %s, %s" % (v(ts), lit(0.15915494), v(ts)))
-            I("v_fma_f32 %s, -%s, s%d, %s" % (v(tc), v(tc), S_CT, v(yc)))
-            I("v_sin_f32 %s, %s" % (v(ts), v(ts)))
-            I("v_mul_f32 %s, %s, %s" % (v(tc), lit(0.15915494), v(tc)))
-            I("v_sin_f32 %s, %s" % (v(tc), v(tc)))
-            if col % 2 == 0:
-                I("v_mul_f32 %s, %s, %s" % (v(hs), v(u), v(ts)))
-                I("v_mul_f32 %s, %s, %s" % (v(hc), v(u), v(tc)))
-            else:
-                kk = col // 4
-                ps, pc = packs[npack % 6], packs[(npack + 1) % 6]
-                half = (col % 4) // 2
-                I("v_mul_f32 %s, %s, %s" % (v(ts), v(u), v(ts)))
-                I("v_mul_f32 %s, %s, %s" % (v(tc), v(u), v(tc)))
-                if half == 0:
-                    ops.append(("palloc", ps))
-                    ops.append(("palloc", pc))
-                I("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(ps[half]), v(hs), v(ts)))
-                I("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(pc[half]), v(hc), v(tc)))
-                if half == 1:
-                    for pair, quad in ((ps, kk), (pc, 12 + kk)):
-                        Q, r_ = divmod(quad, 8)
-                        byte = 64 * Q + 16 * (r_ % 4) + 8 * (r_ // 4)
-                        ops.append(("store", "buffer_store_dwordx2 v[%d:%d], %s, %%0, s%d offen offset:%d" % (pair[0], pair[1], v(vrow), S_GB + g, byte), pair))
-                    npack += 2
+            I("v_add_f32 %s, s%d, %s" % (v(m_dst[a]), R + a, v(w[a])))
+        I("v_add_f32 %s, %s, %s" % (v(RR[1] + 1), v(m_dst[0]), v(m_dst[0])))
+        I("v_add_f32 %s, %s, %s" % (v(RR[2]), v(m_dst[1]), v(m_dst[1])))
+        I("v_add_f32 %s, %s, %s" % (v(RR[2] + 1), v(m_dst[2]), v(m_dst[2])))
+        k0 = -0.5 * f32(1.44269502)
+        for dst, a, k in ((QQ[0], 0, k0), (QQ[0] + 1, 1, k0), (QQ[1], 2, k0), (QQ[1] + 1, 0, 4 * k0), (QQ[2], 1, 4 * k0), (QQ[2] + 1, 2, 4 * k0)):
+            I("v_mul_f32 %s, %s, %s" % (v(dst), lit(k), v(cov[a])))
+        if g == 0:       # the ray row is consumed: group 1's may take its place
+            ops += self.enc_fetch_ops(cur, 1, "r")
+        if not ENC_PACKED:
+            # 48 columns in order: column 3 d + a of the sine block, 48 + 3 d + a of the cosine block (octave d, axis a); the scaled
+            # covariance -0.5 log2 e cov_a (QQ) times 4^d and the mean (RR) times 2^d are exact scalings
+            mean = m_dst
+            covk = [QQ[0], QQ[0] + 1, QQ[1]]
+            y, u, ts, tc, yc, hs, hc = U, U + 1, F, F + 1, YC, A, A + 1
+            for col in range(48):
+                d, a = divmod(col, 3)
+                if d == 0:
+                    ysrc = v(mean[a])
+                else:
+                    I("v_mul_f32 %s, %s, %s" % (v(y), lit(float(1 << d)), v(mean[a])))
+                    ysrc = v(y)
+                if d == 0:
+                    I("v_exp_f32 %s, %s" % (v(u), v(covk[a])))
+                else:
+                    I("v_mul_f32 %s, %s, %s" % (v(u), lit(float(4 ** d)), v(covk[a])))
+                    I("v_exp_f32 %s, %s" % (v(u), v(u)))
+                I("v_mul_f32 %s, %s, %s" % (v(ts), lit(0.0031830988), ysrc))
+                I("v_add_f32 %s, %s, %s" % (v(yc), lit(1.57079637), ysrc))
+                I("v_floor_f32 %s, %s" % (v(ts), v(ts)))
+                I("v_mul_f32 %s, %s, %s" % (v(tc), lit(0.0031830988), v(yc)))
+                I("v_fma_f32 %s, -%s, s%d, %s" % (v(ts), v(ts), S_CT2, ysrc))
+                I("v_floor_f32 %s, %s" % (v(tc), v(tc)))
+                I("v_mul_f32 %s, %s, %s" % (v(ts), lit(0.15915494), v(ts)))
+                I("v_fma_f32 %s, -%s, s%d, %s" % (v(tc), v(tc), S_CT2, v(yc)))
+                I("v_sin_f32 %s, %s" % (v(ts), v(ts)))
+                I("v_mul_f32 %s, %s, %s" % (v(tc), lit(0.15915494), v(tc)))
+                I("v_sin_f32 %s, %s" % (v(tc), v(tc)))
+                ps, pc = packs[(col // 4) % 2]
+                if col % 2 == 0:
+                    I("v_mul_f32 %s, %s, %s" % (v(hs), v(u), v(ts)))
+                    I("v_mul_f32 %s, %s, %s" % (v(hc), v(u), v(tc)))
+                else:
+                    half = (col % 4) // 2
+                    I("v_mul_f32 %s, %s, %s" % (v(ts), v(u), v(ts)))
+                    I("v_mul_f32 %s, %s, %s" % (v(tc), v(u), v(tc)))
+                    if half == 0:
+                        ops.append(("palloc", ps))
+                        ops.append(("palloc", pc))
+                    I("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(ps + half), v(hs), v(ts)))
+                    I("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(pc + half), v(hc), v(tc)))
+                    if half == 1:
+                        m = col // 4
+                        for pair, piece in ((ps, m), (pc, 12 + m)):
+                            ops.append(("store", "s_add_u32 s%d, s%d, %d\n\tbuffer_store_dwordx2 v[%d:%d], %s, %%0, s%d offen"
+                                        % (S_ST, S_GB + g, piece * 512, pair, pair + 1, v(vrow), S_ST), pair))
+            return ops
+        # 24 column pairs: pair i = columns (2 i, 2 i + 1) of the sine block and of the cosine block; i = 3 j + r: octave pair j, slot r
+        for i in range(24):
+            r = i % 3
+            RRr, QQr = RR[r], QQ[r]
+            ps, pc = packs[(i // 2) % 2]
+            half = i % 2
+            if half == 0:
+                ops.append(("palloc", ps))
+                ops.append(("palloc", pc))
+            I("v_exp_f32 %s, %s" % (v(U), v(QQr)))
+            I("v_exp_f32 %s, %s" % (v(U + 1), v(QQr + 1)))
+            I("v_pk_mul_f32 %s, %s, %s" % (v2(F), v2(RRr), s2(S_C1)))
+            I("v_pk_add_f32 %s, %s, %s" % (v2(YC), v2(RRr), s2(S_HP)))
+            I("v_floor_f32 %s, %s" % (v(F), v(F)))
+            I("v_floor_f32 %s, %s" % (v(F + 1), v(F + 1)))
+            I("v_pk_fma_f32 %s, %s, %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (v2(A), v2(F), s2(S_CT2), v2(RRr)))
+            I("v_pk_mul_f32 %s, %s, %s" % (v2(F), v2(YC), s2(S_C1)))
+            I("v_pk_mul_f32 %s, %s, %s" % (v2(A), v2(A), s2(S_C2)))
+            I("v_floor_f32 %s, %s" % (v(F), v(F)))
+            I("v_floor_f32 %s, %s" % (v(F + 1), v(F + 1)))
+            I("v_sin_f32 %s, %s" % (v(A), v(A)))
+            I("v_sin_f32 %s, %s" % (v(A + 1), v(A + 1)))
+            I("v_pk_fma_f32 %s, %s, %s, %s neg_lo:[1,0,0] neg_hi:[1,0,0]" % (v2(YC), v2(F), s2(S_CT2), v2(YC)))
+            I("v_pk_mul_f32 %s, %s, %s" % (v2(RRr), v2(RRr), s2(S_4)))              # the next octave pair's means
+            I("v_pk_mul_f32 %s, %s, %s" % (v2(A), v2(U), v2(A)))
+            I("v_pk_mul_f32 %s, %s, %s" % (v2(YC), v2(YC), s2(S_C2)))
+            I("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(ps + half), v(A), v(A + 1)))
+            I("v_sin_f32 %s, %s" % (v(YC), v(YC)))
+            I("v_sin_f32 %s, %s" % (v(YC + 1), v(YC + 1)))
+            I("v_pk_mul_f32 %s, %s, %s" % (v2(QQr), v2(QQr), s2(S_16)))
+            I("v_pk_mul_f32 %s, %s, %s" % (v2(YC), v2(U), v2(YC)))
+            I("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(pc + half), v(YC), v(YC + 1)))
+            if half == 1:
+                m = i // 2
+                for pair, piece in ((ps, m), (pc, 12 + m)):
+                    ops.append(("store", "s_add_u32 s%d, s%d, %d\n\tbuffer_store_dwordx2 v[%d:%d], %s, %%0, s%d offen"
+                                % (S_ST, S_GB + g, piece * 512, pair, pair + 1, v(vrow), S_ST), pair))
         return ops
+
+    def enc_group_base(self, g, emit=None):
+        """s[S_GB + g] <- byte offset of group g's area in the workgroup's scratch (the soffset of the unit's stores)"""
+        (emit or self.e)("s_add_u32 s%d, s%d, %d" % (S_GB + g, S_TB, g * ENC_GROUP))
+
+    def enc_constants(self):
+        for sreg, val in ((S_C1, 0.0031830988), (S_CT2, 314.159271), (S_C2, 0.15915494), (S_HP, 1.57079637), (S_4, 4.0), (S_16, 16.0)):
+            self.e("s_mov_b32 s%d, %s" % (sreg, lit(val)))
+            self.e("s_mov_b32 s%d, %s" % (sreg + 1, lit(val)))
 
     def emit_enc(self, op, early):
         """one instruction of the encoder's stream into the tile body, with the books of vmcnt / lgkmcnt kept"""
         if early:
             for h in self.enc_held:
-                self.e(h[1])
+                for ln in h[1].split("\n\t"):
+                    self.e(ln)
                 self.vm_issue("store")
             self.enc_held = []
         kind = op[0]
         if kind == "i":
-            self.e(op[1])
-        elif kind == "store":
-            if early:
+            if ENC_VALU or not op[1].startswith("v_"):
                 self.e(op[1])
+        elif kind == "store":
+            if not ENC_STORE:
+                pass
+            elif early:
+                for ln in op[1].split("\n\t"):
+                    self.e(ln)
                 self.vm_issue("store")
             else:
                 self.enc_held.append(op)
@@ -926,7 +1028,7 @@ class Gen:
                         elif it[0] == "enc":
                             self.emit_enc(it[1], enc_early)
                         elif it[0] == "encfetch":
-                            for op in self.enc_fetch_ops(False, it[1]):
+                            for op in self.enc_fetch_ops(False, it[1], "rt" if it[1] == 0 else "t"):
                                 self.emit_enc(op, True)
                         elif it[0] == "encbase":
                             self.enc_group_base(0)
@@ -944,8 +1046,9 @@ class Gen:
                     # every row the encoder stored is in the L2 before pass 9 fetches the first of them (a store retires at any time
                     # relative to the loads: only a full drain says so)
                     assert not self.enc_held, "encoder stores left over at the end of the window"
-                    self.e("s_waitcnt vmcnt(0)")
-                    self.vm, self.pending = [], {}
+                    if ENC_DRAIN:
+                        self.e("s_waitcnt vmcnt(0)")
+                        self.vm, self.pending = [], {}
                 if not NOBARRIER:
                     self.e("s_barrier")
                 state["period"] = blk["period"] + 1
@@ -979,15 +1082,22 @@ class Gen:
         e("v_and_b32 v%d, 15, v%d" % (V_TMP1, V_TMP0))
         e("v_lshrrev_b32 v%d, 4, v%d" % (V_LG16, V_TMP0))
         e("v_lshlrev_b32 v%d, 4, v%d" % (V_LG16, V_LG16))
-        if self.fused:
-            e("v_mul_u32_u24 v%d, %d, v%d" % (V_VX, ENC_ROW, V_TMP1))
+        if self.fused:      # lane group lg reads the pieces lg, 4 + lg of a 32-column group: 512 bytes apart; sample s: 8 bytes apart
+            e("v_lshlrev_b32 v%d, 3, v%d" % (V_VX, V_TMP1))
+            e("v_lshlrev_b32 v%d, 5, v%d" % (V_TMP0, V_LG16))      # (the lane number in V_TMP0 has served; V_TMP1 = lane & 15 is still needed below)
+            e("v_add_u32 v%d, v%d, v%d" % (V_VX, V_VX, V_TMP0))
         else:
             e("v_lshlrev_b32 v%d, 8, v%d" % (V_VX, V_TMP1))
-        e("v_add_u32 v%d, v%d, v%d" % (V_VX, V_VX, V_LG16))
+            e("v_add_u32 v%d, v%d, v%d" % (V_VX, V_VX, V_LG16))
         e("v_mul_u32_u24 v%d, %d, v%d" % (V_VST, self.rs, V_TMP1))
         e("v_add_u32 v%d, 16, v%d" % (V_VST1, V_VST))
         e("v_mov_b32 v%d, 0" % V_ZERO)
         pro = sorted([d for d in real if d["for_next_tile"]], key=lambda d: d["issue"])
+        if self.fused:      # the encoder's inputs of this tile's groups first: the wait for them leaves the LDS-DMA pieces behind them in flight
+            for g in (0, 1):
+                for op in self.enc_fetch_ops(True, g, "rt" if g == 0 else "t"):
+                    e(op[1])
+            self.pro_ndma = sum(npw_of(d["chunk"]) for d in pro)
         for d in pro:
             npw = npw_of(d["chunk"])
             for i in range(npw):
@@ -996,24 +1106,33 @@ class Gen:
                     self.dma_setup(IMG_OFF[d["chunk"]] + c0 * 1024, d["slot"] * SLOT_BYTES + c0 * 1024, npw)
                     e("s_nop 0")
                 e("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d" % (V_LANE16, S_CUR, S_CUR + 1, (i - c0) * 1024))
-        if self.fused:      # the first tile's rows: both groups encoded here, nothing beside them
+        if self.fused:      # the first tile's rows: both groups encoded here, nothing beside them (the weight chunks land meanwhile)
             self.enc_group_base(0)
             self.enc_group_base(1)
             for g in (0, 1):
-                for op in self.enc_fetch_ops(True, g):
-                    e(op[1])
-            e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-            for g in (0, 1):
-                for op in self.enc_unit_ops(g):
-                    if op[0] in ("i", "store"):
-                        e(op[1])
-            e("s_waitcnt vmcnt(0)")
+                for op in self.enc_unit_ops(g, cur=True):
+                    if op[0] == "sflush":
+                        e("s_waitcnt lgkmcnt(0)")
+                    elif op[0] == "tneed":
+                        # issued so far, in this order: fenceposts of group 0 (2 loads), of group 1 (2), the LDS-DMA pieces; loads retire
+                        # in order, so "at most this many in flight" says that the group's fenceposts have landed
+                        e("s_waitcnt vmcnt(%d)" % min(63, self.pro_ndma + (2 if g == 0 else 0)))
+                    elif op[0] == "sload" or (op[0] == "i" and (ENC_PROLOGUE or not op[1].startswith("v_"))) or (op[0] == "store" and ENC_PROLOGUE):
+                        for ln in op[1].split("\n\t"):
+                            e(ln)
+            # (a wave's store and its later load of the same address stay in order in the memory pipeline: no wait between them)
         for c in range(4):
             for q in range(3):
                 for (dst, g) in ((frag(1, c, 4 + q), 0), (treg(c, q), 1)):
-                    e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, (g * 64 + c * 16) * (ENC_ROW if self.fused else FEAT_ROW)))
+                    if self.fused:
+                        e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, g * ENC_GROUP + 8 * q * 512 + c * 128))
+                        e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
+                        e("buffer_load_dwordx2 %s, v%d, %%0, 0 offen sc1" % (reg(dst[0], dst[1], 2), V_TMP1))
+                        e("buffer_load_dwordx2 %s, v%d, %%0, 0 offen offset:2048 sc1" % (reg(dst[0], dst[1] + 2, 2), V_TMP1))
+                        continue
+                    e("s_add_u32 s%d, s%d, %d" % (S_T0, S_TB, (g * 64 + c * 16) * FEAT_ROW))
                     e("v_add_u32 v%d, s%d, v%d" % (V_TMP1, S_T0, V_VX))
-                    e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d%s" % (reg(dst[0], dst[1], 4), V_TMP1, 64 * q, " sc1" if self.fused else XPOLICY))
+                    e("buffer_load_dwordx4 %s, v%d, %%0, 0 offen offset:%d%s" % (reg(dst[0], dst[1], 4), V_TMP1, 64 * q, XPOLICY))
         e("s_waitcnt vmcnt(0)")
         e("s_barrier")
 
@@ -1031,13 +1150,13 @@ class Gen:
             self.out.append(".Lpad%=:")
         e("s_lshl_b32 s%d, %%5, 10" % S_SWAVE)
         if self.fused:
-            e("s_mul_i32 s%d, %%5, %d" % (S_TB, 128 * ENC_ROW))       # this wave's rows in the workgroup's scratch
+            e("s_mul_i32 s%d, %%5, %d" % (S_TB, 2 * ENC_GROUP))     # this wave's two group areas in the workgroup's scratch
             e("s_lshl_b32 s%d, %%6, 3" % S_GC)                        # groups of 64 samples: tile * 8 + wave * 2 + g
             e("s_lshl_b32 s%d, %%5, 1" % S_T0)
             e("s_add_u32 s%d, s%d, s%d" % (S_GC, S_GC, S_T0))
             e("s_lshl_b32 s%d, %%7, 3" % S_TBN)
             e("s_add_u32 s%d, s%d, s%d" % (S_TBN, S_TBN, S_GC))       # (S_TBN: the next tile's first group)
-            e("s_mov_b32 s%d, %s" % (S_CT, lit(314.159271)))
+            self.enc_constants()
         elif XSAME:
             e("s_mov_b32 s%d, 0" % S_TB)
         else:

@@ -7,7 +7,6 @@
 // area private to the workgroup (96 KiB, rewritten every tile: it lives in the L2), from which the body fetches what the unfused body
 // fetches from the feature rows.  The view-direction k-step comes from a per-RAY table (27 values per ray, not per sample).
 // Outputs are bit-identical to ddnerf_encode(feat_dtype = 1) followed by ddnerf_mlp_bf16_forward (tests/test_hip_fused_mlp.py).
-// Compiled with -ffp-contract=off (the ray table repeats rays_encode.hip's arithmetic operation for operation).
 #include "mlp_bf16_common.h"
 
 #include "mlp_bf16_g2_tables.gen.inc"
@@ -16,54 +15,9 @@
 #define G2E_LDS_BYTES (4 * G2E_SLOT_BYTES)
 #define G2E_TILE 512
 #define G2E_SCRATCH_PER_WG (G2E_TILE * G2E_ROW_BYTES)
-#define G2E_TABLE_FLOATS 32   // per ray: 16 floats (o, d, radius^2, d^2, 1 - d^2 / |d|^2, three unused), then 32 bf16 view-direction columns in k-order
+#define G2E_TABLE_FLOATS 32   // per ray (rays_encode.hip, ddnerf_ray_table): 16 floats, then 32 bf16 view-direction columns in k-order
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// ---- the per-ray table -----------------------------------------------------------------------------------------------------------
-// general_utils/math_utils.py:34-54 (lift_gaussian: d^2, the null-space factor) and general_utils/nerf_helpers.py:127-171 (the view
-// directions' positional encoding), the values encode_kernel<1> computes per sample / per block (rays_encode.hip phase 1 and 1b).
-__global__ void g2e_ray_table_kernel(const float *__restrict__ rays, int n, float *__restrict__ table) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *r = rays + 12 * (size_t)i;
-    float *t = table + G2E_TABLE_FLOATS * (size_t)i;
-    const float d0 = r[3], d1 = r[4], d2 = r[5];
-    const float q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
-    const float dmag = fmaxf(1e-10f, (q0 + q1) + q2);
-    t[0] = r[0], t[1] = r[1], t[2] = r[2];
-    t[3] = d0, t[4] = d1, t[5] = d2;
-    t[6] = r[6] * r[6];
-    t[7] = q0, t[8] = q1, t[9] = q2;
-    t[10] = 1.0f - q0 / dmag, t[11] = 1.0f - q1 / dmag, t[12] = 1.0f - q2 / dmag;
-    t[13] = t[14] = t[15] = 0.0f;
-    float dirv[32];
-#pragma unroll
-    for (int k = 27; k < 32; ++k) dirv[k] = 0.0f;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float v = r[9 + a];
-        dirv[a] = v;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const float x = v * (float)(1 << f);
-            dirv[3 + f * 6 + a] = __builtin_amdgcn_sinf(x * 0.15915494f);
-            dirv[3 + f * 6 + 3 + a] = __builtin_amdgcn_sinf((x + 1.57079637f) * 0.15915494f);
-        }
-    }
-    unsigned short *row = (unsigned short *)(t + 16);
-#pragma unroll
-    for (int p = 0; p < 32; ++p) row[p] = __builtin_bit_cast(unsigned short, (__bf16)dirv[korder32(p)]);
-}
-
-DDN_EXPORT size_t ddnerf_ray_table_bytes(int n) { return (size_t)(n > 0 ? n : 0) * G2E_TABLE_FLOATS * sizeof(float); }
-DDN_EXPORT int ddnerf_ray_table(const float *rays, int n, void *table, ddnerf_stream_t stream) {
-    DDN_REQUIRE(rays && table, DDNERF_E_ARG);
-    DDN_REQUIRE(n > 0, DDNERF_E_ARG);
-    DDN_REQUIRE(ddn_aligned(table, 128), DDNERF_E_ALIGN);
-    hipLaunchKernelGGL(g2e_ray_table_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, rays, n, (float *)table);
-    return ddn_launch_status();
-}
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------------
 struct G2EArgs {
@@ -75,6 +29,11 @@ struct G2EArgs {
     long M, ntiles;
     unsigned n, s1, magic, d64;
 };
+
+#ifdef BF16_STAMP  // diagnostic build only (mlp_bf16_g2.hip's layout): six values per workgroup -- s_memtime / s_memrealtime around its tile loop, tiles done, entry
+__device__ unsigned long long *g_bf16g2e_stamps;
+DDN_EXPORT int ddnerf_debug_set_stamps_g2e(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bf16g2e_stamps), &p, sizeof(p)); }
+#endif
 
 template <bool DEPTH_HEAD>
 __global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
@@ -91,6 +50,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
     const unsigned grid = gridDim.x, tile0 = blockIdx.x;
     const unsigned s1 = a.s1, magic = a.magic, nmax = a.n - 1, d64 = a.d64;
     const unsigned long tab = (unsigned long)(size_t)a.table;
+#ifdef BF16_STAMP
+    const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned done = 0;
+#endif
 #pragma clang loop unroll(disable)
     for (unsigned tile = tile0; tile < (unsigned)a.ntiles; tile += grid) {
         if constexpr (DEPTH_HEAD) {
@@ -108,9 +72,26 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
                   "s"(magic), "s"(nmax), "s"(d64), "s"(tab)
                 : G2E_CLOBBERS);
         }
+#ifdef BF16_STAMP
+        ++done;
+#endif
     }
     // (the last tile issued the next one's chunks, rows and inputs: let them land before the wave ends)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef BF16_STAMP
+    {
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *sp = g_bf16g2e_stamps;
+        if (sp && threadIdx.x == 0) {
+            sp[6 * blockIdx.x + 0] = st_t0;
+            sp[6 * blockIdx.x + 1] = st_r0;
+            sp[6 * blockIdx.x + 2] = st_t1;
+            sp[6 * blockIdx.x + 3] = st_r1;
+            sp[6 * blockIdx.x + 4] = done;
+            sp[6 * blockIdx.x + 5] = st_entry;
+        }
+    }
+#endif
 }
 
 // (32-bit byte offsets into t_vals and the outputs, the next tile's included)

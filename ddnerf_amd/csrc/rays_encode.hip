@@ -1,7 +1,7 @@
 // Ray packing, first-cycle sampling and the fused cone-cast + IPE + view-dir encoding kernel (K1).
 // Compiled with -ffp-contract=off: the Gaussian mean feeds sin(x * 2^l) with l up to 15, so the
 // reference's operation order must be kept bit for bit (SURVEY.md 7 "hard parts").
-#include "common.h"
+#include "mlp_bf16_common.h"   // (korder32: the 16-bit rows' column order; includes common.h)
 
 // ---------------------------------------------------------------------------------------------------
 // a1  GeneralMipNerfModel.get_rays_batches   models/models.py:144-162
@@ -105,6 +105,97 @@ __global__ void pack_first_cycle_kernel(const float *__restrict__ ro, const floa
         if (j == nc) t = fr;
     }
     t_vals[idx] = t;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The per-RAY table of the fused encoder + MLP kernel (mlp_bf16_g2e.hip): what encode_kernel<1> derives from a packed ray row once
+// per sample (phase 1: d^2, the null-space factor 1 - d^2 / |d|^2 of lift_gaussian, general_utils/math_utils.py:34-54) or once per
+// block (phase 1b: the view directions' positional encoding, general_utils/nerf_helpers.py:127-171), once per ray: 16 floats
+// [o 0:3 | d 3:6 | radius^2 6 | d^2 7:10 | 1 - d^2/|d|^2 10:13 | 0 0 0], then the ray's 32 view-direction columns as a bf16 row in
+// MFMA k-order (the same arithmetic, operation for operation: the fused kernel's outputs equal the two-launch path's bit for bit).
+// ---------------------------------------------------------------------------------------------------
+#define DDN_RAY_TABLE_FLOATS 32
+__device__ __forceinline__ void ray_table_row(const float *__restrict__ r, float *__restrict__ t) {
+    const float d0 = r[3], d1 = r[4], d2 = r[5];
+    const float q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+    const float dmag = fmaxf(1e-10f, (q0 + q1) + q2);
+    t[0] = r[0], t[1] = r[1], t[2] = r[2];
+    t[3] = d0, t[4] = d1, t[5] = d2;
+    t[6] = r[6] * r[6];
+    t[7] = q0, t[8] = q1, t[9] = q2;
+    t[10] = 1.0f - q0 / dmag, t[11] = 1.0f - q1 / dmag, t[12] = 1.0f - q2 / dmag;
+    t[13] = t[14] = t[15] = 0.0f;
+    float dirv[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) dirv[k] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = r[9 + a];
+        dirv[a] = v;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float x = v * (float)(1 << f);
+            dirv[3 + f * 6 + a] = __builtin_amdgcn_sinf(x * 0.15915494f);                    // (encode_kernel<1>: fast_sin)
+            dirv[3 + f * 6 + 3 + a] = __builtin_amdgcn_sinf((x + 1.57079637f) * 0.15915494f);
+        }
+    }
+    unsigned short *row = (unsigned short *)(t + 16);
+#pragma unroll
+    for (int p = 0; p < 32; ++p) row[p] = __builtin_bit_cast(unsigned short, (__bf16)dirv[korder32(p)]);
+}
+
+__global__ void ray_table_kernel(const float *__restrict__ rays, int n, float *__restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ray_table_row(rays + 12 * (size_t)i, table + DDN_RAY_TABLE_FLOATS * (size_t)i);
+}
+
+DDN_EXPORT size_t ddnerf_ray_table_bytes(int n) { return (size_t)(n > 0 ? n : 0) * DDN_RAY_TABLE_FLOATS * sizeof(float); }
+DDN_EXPORT int ddnerf_ray_table(const float *rays, int n, void *table, ddnerf_stream_t stream) {
+    DDN_REQUIRE(rays && table, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ddn_aligned(table, 128), DDNERF_E_ALIGN);
+    hipLaunchKernelGGL(ray_table_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, rays, n, (float *)table);
+    return ddn_launch_status();
+}
+
+// a1 + a2 + the ray table in ONE launch (the head of a one-chunk render pass on the fused bf16 path): pack_first_cycle_kernel without
+// jitter, whose j = 0 thread also writes its ray's table row from the values it has just packed -- rays, t_vals and table bit for bit
+// those of ddnerf_pack_rays_first_cycle (t_rand = NULL) followed by ddnerf_ray_table.
+__global__ void pack_first_cycle_table_kernel(const float *__restrict__ ro, const float *__restrict__ rd, const float *__restrict__ rad,
+                                              float near_, float far_, const float *__restrict__ t_lin, float *__restrict__ rays,
+                                              float *__restrict__ t_vals, float *__restrict__ table, int n, int nc, int lindisp) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int s1 = nc + 1;
+    if (idx >= (size_t)n * s1) return;
+    int i = (int)(idx / s1), j = (int)(idx % s1);
+    if (j == 0) {
+        float d0 = rd[3 * i], d1 = rd[3 * i + 1], d2 = rd[3 * i + 2];
+        float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+        float r[12];
+        r[0] = ro[3 * i]; r[1] = ro[3 * i + 1]; r[2] = ro[3 * i + 2];
+        r[3] = d0; r[4] = d1; r[5] = d2;
+        r[6] = rad[i];
+        r[7] = near_; r[8] = far_;
+        r[9] = d0 / nrm; r[10] = d1 / nrm; r[11] = d2 / nrm;
+        float *dst = rays + 12 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dst[k] = r[k];
+        ray_table_row(r, table + DDN_RAY_TABLE_FLOATS * (size_t)i);
+    }
+    t_vals[idx] = first_cycle_t(near_, far_, t_lin[j], lindisp);
+}
+
+DDN_EXPORT int ddnerf_pack_rays_first_cycle_table(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                                                  const float *t_lin, float *rays, float *t_vals, void *table, int n, int nc, int lindisp,
+                                                  ddnerf_stream_t stream) {
+    DDN_REQUIRE(origins && directions && radii && t_lin && rays && t_vals && table, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(lindisp >= 0 && lindisp <= 2, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(table, 128), DDNERF_E_ALIGN);
+    size_t total = (size_t)n * (nc + 1);
+    hipLaunchKernelGGL(pack_first_cycle_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, origins,
+                       directions, radii, near_, far_, t_lin, rays, t_vals, (float *)table, n, nc, lindisp);
+    return ddn_launch_status();
 }
 
 DDN_EXPORT int ddnerf_pack_rays_first_cycle(const float *origins, const float *directions, const float *radii, float near_, float far_,

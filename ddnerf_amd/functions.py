@@ -125,6 +125,15 @@ class _MLPFunction(torch.autograd.Function):
         return (None, None) + tuple(views)
 
 
+def needs_grad(net):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
+
+
+def encode_mlp_bf16(table, t_vals, net):
+    """models/models.py:117-142 in one launch (bf16 tier, inference): ray table [n,32] + fenceposts [n,S+1] -> raw [n*S,4|6]"""
+    return ops.encode_mlp_bf16_forward(table, t_vals, _packed_weights(net), net.depth_head)
+
+
 def mlp(feat, net):
     """feat [M,128] (fp32, or k-ordered bf16 / fp16 for the bf16 / fp16 kernels) -> raw [M,4|6]"""
     if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):

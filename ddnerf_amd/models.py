@@ -53,6 +53,9 @@ class TorchRng:
 import os as _os
 
 FUSE_RENDER = _os.environ.get("DDNERF_FUSE_RENDER", "1") != "0"
+# bf16 tier: run_network (models/models.py:117-142) as ONE launch, the encoder inside the MLP kernel (ops.encode_mlp_bf16_forward;
+# bit-identical to encode + MLP).  "all" both passes, "fine" the fine pass only, "0" never.
+FUSE_ENCODER = _os.environ.get("DDNERF_FUSE_ENCODER", "all")
 KERNEL_NOISE = _os.environ.get("DDNERF_KERNEL_NOISE", "1") != "0"   # (0: the compositing noise comes from a torch generator launch again)
 
 _const_cache = {}
@@ -136,6 +139,7 @@ class GeneralMipNerfModel(torch.nn.Module):
                 finish()
         finally:
             self._deferred_records = None
+            self._ray_table = None         # (the fused bf16 path's per-ray table of the last chunk: it belongs to this call's rays)
             self._flush_first_pending()    # (no-op: predict's first run_network filled the packed rows it was handed)
         output = pred[0]
         if len(pred) > 1:
@@ -250,7 +254,25 @@ class GeneralMipNerfModel(torch.nn.Module):
         if shape not in ("cone", "cylinder"):
             raise AssertionError("ray_shape must be 'cone' or 'cylinder'")  # math_utils.py:28
         pend = getattr(self, "_first_pending", None)
-        if pend is not None and pend[0].data_ptr() == ray_batch.data_ptr() and pend[1].data_ptr() == t_vals.data_ptr():
+        first = pend is not None and pend[0].data_ptr() == ray_batch.data_ptr() and pend[1].data_ptr() == t_vals.data_ptr()
+        n, S = t_vals.shape[0], t_vals.shape[1] - 1
+        if (kind == "bf16" and shape == "cone" and FUSE_ENCODER != "0" and (FUSE_ENCODER == "all" or not first)
+                and ops.encode_mlp_bf16_supported(S, n * S) and not F.needs_grad(network)):
+            # the fused kernel: the encoded rows never exist; a per-RAY table (built once per ray batch, by the launch that packs the rays
+            # when this is the coarse pass of a one-chunk batch) carries what the encoder derives from a ray
+            if first:
+                self._first_pending = None
+                rays, t0, ro, rd, rad, t_lin, lindisp = pend
+                table = ops.pack_rays_first_cycle_table(ro, rd, rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin, lindisp, out=(rays, t0))[2]
+            else:
+                if pend is not None:
+                    self._flush_first_pending()
+                held = getattr(self, "_ray_table", None)
+                table = held[1] if held is not None and held[0] is ray_batch else ops.ray_table(ray_batch)
+            self._ray_table = (ray_batch, table)
+            raw = F.encode_mlp_bf16(table, t_vals, network)
+            return raw.reshape(n, S, raw.shape[-1])
+        if first:
             # the coarse pass of a one-chunk batch: this launch also fills ray_batch and t_vals (get_rays_batches handed them out empty)
             self._first_pending = None
             rays, t0, ro, rd, rad, t_lin, lindisp = pend

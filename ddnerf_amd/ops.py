@@ -158,6 +158,24 @@ def ray_table(rays):
     return table
 
 
+def pack_rays_first_cycle_table(ray_origins, ray_directions, ray_rad, near, far, t_lin, lindisp=False, out=None):
+    """pack_rays_first_cycle (no jitter) + ray_table in ONE launch -> (rays [n,12], t_vals [n,nc+1], table [n,32]); `out` = (rays, t_vals)
+    tensors to fill (handed out earlier by GeneralMipNerfModel.get_rays_batches)"""
+    o = _f32c(ray_origins.reshape(-1, 3), "origins")
+    d = _f32c(ray_directions.reshape(-1, 3), "directions")
+    r = _f32c(ray_rad.reshape(-1), "radii")
+    t_lin = _f32c(t_lin, "t_lin")
+    n, nc = o.shape[0], t_lin.shape[0] - 1
+    if out is None:
+        out = (torch.empty((n, 12), dtype=torch.float32, device=o.device), torch.empty((n, nc + 1), dtype=torch.float32, device=o.device))
+    rays, t_vals = out
+    table = torch.empty((n, 32), dtype=torch.float32, device=o.device)
+    _lib.check(_lib.lib().ddnerf_pack_rays_first_cycle_table(_ptr(o), _ptr(d), _ptr(r), float(near), float(far), _ptr(t_lin), _ptr(rays),
+                                                             _ptr(t_vals), _ptr(table), n, nc, int(lindisp), _stream()),
+               "ddnerf_pack_rays_first_cycle_table")
+    return rays, t_vals, table
+
+
 _FUSED_SCRATCH = {}
 
 

@@ -128,6 +128,11 @@ int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, int depth_he
  *     whose outputs these are BIT FOR BIT. */
 size_t ddnerf_ray_table_bytes(int n);
 int ddnerf_ray_table(const float *rays, int n, void *table, ddnerf_stream_t stream);
+/* a1 + a2 + the table in ONE launch (the head of a one-chunk render pass): ddnerf_pack_rays_first_cycle with t_rand = NULL followed by
+ * ddnerf_ray_table, bit for bit. */
+int ddnerf_pack_rays_first_cycle_table(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                                       const float *t_lin, float *rays, float *t_vals, void *table, int n, int nc, int lindisp,
+                                       ddnerf_stream_t stream);
 size_t ddnerf_encode_mlp_bf16_scratch_bytes(void);
 int ddnerf_encode_mlp_bf16_forward(const void *ray_table, const float *t_vals, const void *packed, int depth_head, float *raw, int n, int S,
                                    void *scratch, ddnerf_stream_t stream);

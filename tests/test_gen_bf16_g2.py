@@ -90,18 +90,22 @@ def test_operand_ranges_and_counts(gen, body):
     if fused:
         enc = [t for t in lines if t.startswith("buffer_store_dwordx2") and "%0" in t]
         # the encoder: 2 groups x 24 four-column pieces per tile, and the same once more in the first tile's prologue; every piece of a
-        # 192-byte row exactly once per group
+        # group's area ([piece][sample][8 bytes]) exactly once per group, the store's soffset set by the instruction in front of it
         assert len(enc) == 96
         start = lines.index(".Lsteady%=:") + 1
         for part in (lines[:start], lines[start:]):
             offs = {}
-            for t in part:
-                if t.startswith("buffer_store_dwordx2") and "%0" in t:
-                    soff = t.split(",")[3].split()[0]
-                    m = re.search(r"offset:(\d+)", t)
-                    offs.setdefault(soff, []).append(int(m.group(1)) if m else 0)
-            assert sorted(offs) == ["s46", "s47"] and all(sorted(v) == list(range(0, 192, 8)) for v in offs.values())
+            for a, b in zip(part, part[1:]):
+                if b.startswith("buffer_store_dwordx2") and "%0" in b:
+                    m = re.fullmatch(r"s_add_u32 s76, (s4[67]), (\d+)", a)
+                    assert m and b.split(",")[3].split()[0] == "s76" and "offset" not in b, (a, b)
+                    offs.setdefault(m.group(1), []).append(int(m.group(2)))
+            assert sorted(offs) == ["s46", "s47"] and all(sorted(v) == list(range(0, 24 * 512, 512)) for v in offs.values())
         assert sum(1 for t in lines if t.startswith("v_sin_f32")) == 4 * 96 and sum(1 for t in lines if t.startswith("v_exp_f32")) == 4 * 48
+        for t in lines:       # packed fp32 instructions: even-aligned register pairs, scalar constants as pairs
+            if t.startswith("v_pk_"):
+                for m in re.finditer(r"[vs]\[(\d+):(\d+)\]", t):
+                    assert int(m.group(1)) % 2 == 0 and int(m.group(2)) == int(m.group(1)) + 1, t
         assert sum(1 for t in lines if t.startswith("v_div_fmas_f32")) == 4 * 4
 
 
@@ -110,7 +114,7 @@ def test_memory_counter_replay(gen, body):
     retire in order, a wait vmcnt(n) leaves at most n of them in flight.  Every register written by a load must be out of flight when a
     matrix instruction, a store or a VALU instruction reads it; every LDS read likewise (lgkmcnt).  The tile body is replayed three
     times in a row (the second and third start with what the previous one left in flight)."""
-    lines, _ = body
+    lines, (_, _, fused) = body
     start = lines.index(".Lsteady%=:") + 1
     steady = lines[start:]
     vm, lg, sm = [], [], []  # in-flight loads: lists of (destination registers)
@@ -149,6 +153,8 @@ def test_memory_counter_replay(gen, body):
                 reads = _regs(parts[2]) if len(parts) > 2 else []
             elif op.startswith(("buffer_store", "global_store")):
                 reads = _regs(parts[0]) + _regs(parts[1])
+                if fused:       # (the fused body books its stores into the in-order queue: gen_bf16_g2.py, vm_inorder)
+                    vm.append(set())
             elif op.startswith(("v_", "s_")) and parts and op not in ("s_barrier", "s_nop", "s_cbranch_scc1"):
                 reads = [r for p in parts[1:] for r in _regs(p)]
                 if op.startswith("v_mfma") or op.startswith("s_add") or op.startswith("s_mul"):
@@ -169,7 +175,7 @@ def test_weight_stream_replay(gen, body):
     issuing wave's vmcnt order and (b) been followed by an s_barrier (every wave's pieces then have); and a piece may be issued into a
     slot only when an s_barrier separates it from the last read of the slot's previous content (all waves run this code in step with
     the barriers).  Slots are recovered from the scalar arithmetic in front of each `s_add_u32 m0` and of each base-register update."""
-    lines, _ = body
+    lines, (_, _, fused) = body
     start = lines.index(".Lsteady%=:") + 1
     head, steady = lines[:start - 1], lines[start:]
     S = gen.SLOT_BYTES
@@ -231,7 +237,7 @@ def test_weight_stream_replay(gen, body):
                 p = {"retired": False}
                 flight.append(p)
                 uncertified[slot].append(p)
-            elif op.startswith("buffer_load"):
+            elif op.startswith("buffer_load") or (fused and op.startswith("buffer_store")):
                 flight.append({"retired": False})
             elif op == "ds_read_b128":
                 b = t.split(",")[1].split()[0].strip()
