@@ -53,10 +53,20 @@ def load_fullsize(name):
     n_, nc, nf, sharpen, stride, near, far, dist_reg, smooth, pad = g["meta"]
     assert int(n_) == int(n)
     dd = mt == "dd"
+    if tag == "trained":     # TRAINED weights: the reference's own 3000-iteration run (make_golden.py gen_trained), not the seeded ones
+        sd_coarse, sd_fine = trained_state_dicts()
+    else:
+        sd_coarse = synthetic.make_state_dict(dd, 11, float(sharpen))
+        sd_fine = synthetic.make_state_dict(False, 12, float(sharpen)) if dd else None
     return dict(g=g, tag=tag, dd=dd, kind=kind, n=int(n), nc=int(nc), nf=int(nf), stride=int(stride), near=float(near), far=float(far),
                 dist_reg=float(dist_reg), smooth=float(smooth), pdf_padding=bool(pad), noise=0.0, train=False, mode="validation",
-                sd_coarse=synthetic.make_state_dict(dd, 11, float(sharpen)),
-                sd_fine=synthetic.make_state_dict(False, 12, float(sharpen)) if dd else None, dp_coef=None)
+                sd_coarse=sd_coarse, sd_fine=sd_fine, dp_coef=None)
+
+
+def trained_state_dicts():
+    """(coarse, fine) state_dicts after 3000 iterations of the reference's training loop (tests/golden/trained_weights_dd_blender.npz)"""
+    w = np.load(os.path.join(GOLDEN, "trained_weights_dd_blender.npz"))
+    return ({k[2:]: w[k] for k in w.files if k.startswith("c.")}, {k[2:]: w[k] for k in w.files if k.startswith("f.")})
 
 
 def maxerr(a, b):

@@ -21,10 +21,13 @@ def _load(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
-def test_sampler_indices_bit_exact_at_4096_rays():
+@pytest.mark.parametrize("name", ["sampler4096_cfg2", "sampler4096_trained"])
+def test_sampler_indices_bit_exact_at_4096_rays(name):
+    """the sampler boundary of a 4096-ray coarse pass, exactly as the reference handed it over: seeded-uniform weights (cfg2) and the
+    TRAINED coarse network of the reference's 3000-iteration run (peaked weights, mostly empty rays)"""
     from ddnerf_amd import ops
 
-    g = _load("sampler4096_cfg2")
+    g = _load(name)
     n, nc, ns, near, far, pad = g["meta"]
     n, nc, ns = int(n), int(nc), int(ns)
     d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
@@ -37,7 +40,7 @@ def test_sampler_indices_bit_exact_at_4096_rays():
     assert ind.shape == ref_ind.shape == (n, ns)
     assert np.array_equal(ind, ref_ind), "%d of %d sample indices differ" % (int((ind != ref_ind).sum()), ind.size)
     # every bin is used somewhere in the batch, rows differ from each other: the comparison is not vacuous
-    assert len(np.unique(ref_ind)) == nc and len(np.unique(ref_ind, axis=0)) > n // 2
+    assert len(np.unique(ref_ind)) == nc and len(np.unique(ref_ind, axis=0)) > n // (2 if name.endswith("cfg2") else 8)
     s, ref = out.cpu().numpy(), g["samples"]
     assert np.abs(s - ref).max() <= 2e-6 * far                            # erf / erfinv / exp implementations differ by ulps
     assert np.all(np.diff(s, axis=1) >= 0)

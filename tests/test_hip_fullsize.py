@@ -1,7 +1,8 @@
 """GPU parity at BASELINE.json's stated sizes against outputs of the REFERENCE itself (tests/golden/fullsize_*.npz, generated
 by importing the reference on the same seeded rays and weights; every 61st / 125th ray is stored):
   cfg1 config_blender.yml 256 rays x 64 x 64, cfg2 config_blender.yml 4096 x (64 + 128), cfg3 config_ff.yml NDC rays,
-  cfg4 config_360.yml 8192 rays, cfg5 config_blender_mipnerf.yml (one shared MLP).
+  cfg4 config_360.yml 8192 rays, cfg5 config_blender_mipnerf.yml (one shared MLP); "trained": 4096 blender / NDC rays through the
+  weights of the reference's own 3000-iteration training run (PSNR 35 dB on its scene) instead of seeded-uniform ones.
 fp32 and x3 kernels: RGB / depth / acc / weights within 1e-4 (north_star); the bf16 kernel on its tier (cfg3 is BASELINE's
 bf16 configuration)."""
 import numpy as np
@@ -46,17 +47,24 @@ def test_full_size_matches_reference(name, mlp_dtype):
             assert relerr(out[0][k].cpu().numpy(), g["o0_" + k]) <= 2e-5, k
 
 
-@pytest.mark.parametrize("name", [n for n in fullsize_names() if "cfg3" in n or "cfg2" in n])
+@pytest.mark.parametrize("name", [n for n in fullsize_names() if "cfg3" in n or "cfg2" in n or "trained" in n])
 def test_full_size_bf16_tier(name):
-    """bf16-MFMA MLP at full size against the reference's fp32 outputs: measured <= 3e-4 RGB / 78-93 dB on the small fixtures;
-    the bar is 3x that."""
+    """bf16-MFMA MLP at full size against the reference's fp32 outputs.  Seeded-uniform weights (cfg2, cfg3): measured <= 3e-4 RGB /
+    78-93 dB; the bar is 3x that.  TRAINED weights (the reference's own 3000-iteration run; round 5, tools/tier_errors.py): the errors
+    are 3-6x larger -- RGB <= 1.9e-3, depth <= 2.1e-3 absolute, weights <= 1.5e-3 -- because a trained network's activations are large
+    where the scene is (bf16 keeps 8 bits of each); held to 3e-3 / 4e-3 absolute and 60 dB."""
     c = load_fullsize(name)
     g, st = c["g"], c["stride"]
     out = _run(c, "bf16")
+    trained = c["tag"] == "trained"
     for lvl in (0, 1):
         rgb, ref = out[lvl]["rgb"][::st].cpu().numpy(), g["o%d_rgb" % lvl]
         psnr = -10.0 * np.log10(max(float(np.mean((rgb - ref) ** 2)), 1e-20))
-        assert psnr >= 75.0, (lvl, psnr)
-        assert np.abs(rgb - ref).max() <= 1e-3, (lvl, np.abs(rgb - ref).max())
         depth, dref = out[lvl]["depth"][::st].cpu().numpy(), g["o%d_depth" % lvl]
-        assert np.abs(depth - dref).max() <= 2.5e-3 * max(1.0, np.abs(dref).max()), lvl
+        got = (psnr, float(np.abs(rgb - ref).max()), float(np.abs(depth - dref).max()))
+        if trained:
+            assert psnr >= 60.0 and got[1] <= 3e-3 and got[2] <= 4e-3, (lvl, got)
+        else:
+            assert psnr >= 75.0, (lvl, got)
+            assert got[1] <= 1e-3, (lvl, got)
+            assert got[2] <= 2.5e-3 * max(1.0, np.abs(dref).max()), (lvl, got)

@@ -114,6 +114,30 @@ def test_run_iter(name):
         assert abs(out[0]["mus_reg"] - g["o0_mus_reg"][0]) <= 1e-7
 
 
+@pytest.mark.parametrize("name", ["fullsize_trained_dd_blender_4096_64x128", "fullsize_trained_dd_llff_4096_64x128"])
+def test_run_iter_on_trained_weights(name):
+    """The oracle on the reference's own TRAINED networks (3000 iterations of its training loop, make_golden.py gen_trained: peaked
+    densities, saturated colours, confident depth distributions -- not the seeded-uniform weights of every other fixture): the rays
+    whose outputs the fixture stores (every 61st of 4096), per-ray quantities within 1e-5 of the reference's."""
+    import numpy as np
+    import torch
+    from _cases import load_fullsize
+    from ddnerf_amd import synthetic
+
+    c = load_fullsize(name)
+    g, st = c["g"], c["stride"]
+    ro, rd, rad, _ = synthetic.make_rays(c["kind"], c["n"], 1)
+    ro, rd, rad = ro[::st], rd[::st], rad[::st]
+    out = O.run_iter(ro, rd, rad, c["sd_coarse"], c["sd_fine"], model="dd", nc=c["nc"], nf=c["nf"], near=c["near"], far=c["far"],
+                     blender=c["kind"] == "blender", white_bkgd=False, pdf_padding=c["pdf_padding"], smooth=c["smooth"],
+                     dist_reg=c["dist_reg"], t_lin=torch.linspace(0, 1, c["nc"] + 1).numpy(), t_rand=None, noise0=None,
+                     u_det=torch.linspace(0.0, 0.9999, c["nf"] + 1).numpy(), u_rand=None, noise1=None, want_dp_loss=False)
+    for lvl in (0, 1):
+        for k in ("rgb", "depth", "acc", "weights"):
+            assert maxerr(out[lvl][k], g["o%d_%s" % (lvl, k)]) <= 1e-5, (lvl, k)
+    assert float(g["psnr"][1]) > 30.0 or c["kind"] != "blender"     # (the blender fixture: the reference's fit of its training scene)
+
+
 def test_fp32_remainder_recipe_is_bit_exact():
     """The encode kernel replaces fmodf by a four-instruction fp32 recipe (rays_encode.hip: remainder_pos); this is the
     same arithmetic in numpy, checked bit-for-bit against torch.remainder on values that include near-multiples of T."""

@@ -16,7 +16,7 @@ from test_hip_run_iter import build_model  # noqa: E402
 
 
 def main():
-    print("%-22s %-5s %s" % ("fixture", "tier", "  ".join("%-12s" % ("L%d %s" % (l, k)) for l in (0, 1) for k in ("rgb", "depth", "acc", "weights"))))
+    print("%-44s %-5s %s" % ("fixture", "tier", "  ".join("%-12s" % ("L%d %s" % (l, k)) for l in (0, 1) for k in ("rgb", "depth", "acc", "weights"))))
     for name in fullsize_names():
         c = load_fullsize(name)
         g, st = c["g"], c["stride"]
@@ -32,7 +32,7 @@ def main():
             for lvl in (0, 1):
                 for k in ("rgb", "depth", "acc", "weights"):
                     errs.append(float(np.abs(out[lvl][k][::st].cpu().numpy() - g["o%d_%s" % (lvl, k)]).max()))
-            print("%-22s %-5s %s" % (name, tier, "  ".join("%-12.3e" % e for e in errs)), flush=True)
+            print("%-44s %-5s %s" % (name, tier, "  ".join("%-12.3e" % e for e in errs)), flush=True)
 
 
 if __name__ == "__main__":
