@@ -48,7 +48,7 @@ CONFIGS = {
     "config_ff_mipnerf.yml": ("llff", "fp32", 4096),
     "config_360_mipnerf.yml": ("real360", "fp32", 8192),
 }
-KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2e_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"],
                   "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
                   "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
 
@@ -440,6 +440,71 @@ def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
             "build a few per cent of busy share)"}
 
 
+def bf16_fused_in_kernel_clock(model, device, seconds=2.5):
+    """As bf16_in_kernel_clock for the FUSED kernel the bf16 render step runs (mlp_bf16_g2e.hip: the encoder inside the MLP kernel):
+    the diagnostic build of the same sources back to back on a fine pass of 4096 synthetic rays x 128 sorted fenceposts; its tile
+    loop's cycles include the encoder's work and, once per workgroup, the straight-line encoder of the first tile."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from ddnerf_amd import build as hip_build
+    from ddnerf_amd import functions as F
+    from ddnerf_amd import ops, synthetic
+
+    if not os.path.exists(hip_build.DIAG_SO):
+        return None
+    L = C.CDLL(hip_build.DIAG_SO)
+    if not hasattr(L, "ddnerf_debug_set_stamps_g2e"):
+        return None
+    V = C.c_void_p
+    n, S = 4096, 128
+    M = n * S
+    st = torch.cuda.current_stream().cuda_stream
+    o, d, rad, _ = synthetic.make_rays("blender", n, 1)
+    rays = ops.pack_rays(*(torch.from_numpy(x).to(device) for x in (o, d, rad)), 2.0, 6.0)
+    t = (2.0 + 4.0 * torch.sort(torch.rand(n, S + 1, device=device), dim=1).values).contiguous()
+    tab = ops.ray_table(rays)
+    packed = F._packed_weights(model.fine)
+    raw = torch.empty(M, 4, device=device)
+    L.ddnerf_encode_mlp_bf16_scratch_bytes.restype = C.c_size_t
+    scratch = torch.empty(L.ddnerf_encode_mlp_bf16_scratch_bytes(), dtype=torch.uint8, device=device)
+    f = L.ddnerf_encode_mlp_bf16_forward
+    f.argtypes = [V, V, V, C.c_int, V, C.c_int, C.c_int, V, V]
+    L.ddnerf_debug_set_stamps_g2e.argtypes = [V]
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    stamps = torch.zeros(n_cu * 6, dtype=torch.int64, device=device)
+    if L.ddnerf_debug_set_stamps_g2e(stamps.data_ptr()):
+        return None
+    launch = lambda: f(tab.data_ptr(), t.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), n, S, scratch.data_ptr(), st)
+    t0, nl = time.time(), 0
+    while time.time() - t0 < seconds:
+        for _ in range(50):
+            launch()
+        torch.cuda.synchronize()
+        nl += 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 50
+    s = stamps.cpu().numpy().reshape(n_cu, 6).astype(np.float64)
+    s = s[s[:, 4] > 0]
+    clk = float(np.median((s[:, 2] - s[:, 0]) / (s[:, 3] - s[:, 1]) * 100.0))
+    cyc = float(np.median((s[:, 2] - s[:, 0]) / s[:, 4]))
+    ideal = 9640 * 16
+    return {"kernel": "two groups per weight pass with the encoder inside (mlp_bf16_g2e.hip)",
+            "in_kernel_clock_mhz": round(clk), "nominal_clock_mhz": 2400, "tile_samples": 512, "cycles_per_tile": round(cyc),
+            "ideal_cycles_per_tile": ideal, "mfma_busy": round(ideal / cyc, 4), "frac_bound_at_this_clock": round(clk / 2400.0, 4),
+            "back_to_back_launch_ms": round(ms, 4), "back_to_back_frac": round(FLOP_FINE * M / (ms * 1e-3) / 1e12 / PEAK["bf16"], 4),
+            "warm_launches": nl, "how": "diagnostic stamp build of the same kernel sources on 4096 synthetic rays x 128 sorted fenceposts, after the "
+            "timed region; cycles_per_tile = a workgroup's tile-loop cycles / its tiles: the MLP's MFMAs, the next tile's encoder in their "
+            "gaps and a quarter of the first tile's straight-line encoder (four tiles per workgroup)"}
+
+
 def kernel_source_digest(mlp):
     """md5 of the kernel's sources; for the generated assembly body of the two-group bf16 kernel: of the generator's OUTPUT (the files
     the build compiles), so that an experiment switch added to the generator does not disown a profile of the unchanged kernel"""
@@ -588,8 +653,21 @@ def main(argv=None):
             if args.mlp == "x3":
                 roof["issued_tflops"] = round(3 * ach, 2)
                 roof["frac_issued"] = round(3 * ach / PEAK["x3"], 4)
+            fused = False
+            if args.mlp == "bf16":
+                from ddnerf_amd import models as _m
+                from ddnerf_amd import ops as _o
+
+                fused = (_m.FUSE_ENCODER != "0" and str(cfg.nerf.ray_shape) == "cone" and _o.encode_mlp_bf16_supported(args.fine, M_fine))
+                roof["encoder_in_kernel"] = fused
+                if fused:
+                    # (the launch that is timed also ENCODES its samples -- cast_rays + integrated_pos_enc, models/models.py:117-142 -- and
+                    # the unfused path's encode launch is gone from the step; `achieved` / `frac` still count the MLP's FLOP only)
+                    roof["kernel"] = "mlp_bf16g2e_fwd_kernel<fine> (encoder inside the MLP kernel; %d samples/launch)" % M_fine
             if args.mlp == "bf16" and (args.rays, args.fine) == (4096, 128) and not args.no_clock:
-                roof["clock"] = bf16_in_kernel_clock(model.fine.flat_params().detach(), device)
+                roof["clock"] = bf16_fused_in_kernel_clock(model, device) if fused else bf16_in_kernel_clock(model.fine.flat_params().detach(), device)
+                if fused:
+                    roof["clock_unfused_mlp"] = bf16_in_kernel_clock(model.fine.flat_params().detach(), device, seconds=1.5)
                 roof["ceiling_same_box"] = bf16_same_box_ceiling(device, roof["frac"])
         elif head == "train":
             roof = train_roofline(args, cfg, dt / args.steps)

@@ -98,12 +98,13 @@ DIAG_SO = os.path.join(CSRC, "libddnerf_diag.so")
 
 
 def build_diag(force: bool = False, verbose: bool = False) -> str:
-    deps = [os.path.join(CSRC, f) for f in ("mlp_bf16.hip", "mlp_bf16_g2.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h", "common.h",
-                                            "api.hip", "mfma_ceiling.hip")] + [__file__]
+    deps = [os.path.join(CSRC, f) for f in ("mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h",
+                                            "common.h", "api.hip", "mfma_ceiling.hip")] + [__file__]
     if force or _stale(DIAG_SO, deps):
         generate(force, verbose)
         cmd = [HIPCC] + COMMON + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_STAMP", "-DBF16_DISPATCH", "-shared", os.path.join(CSRC, "mlp_bf16.hip"),
-                                  os.path.join(CSRC, "mlp_bf16_g2.hip"), os.path.join(CSRC, "api.hip"), os.path.join(CSRC, "mfma_ceiling.hip"), "-o", DIAG_SO]
+                                  os.path.join(CSRC, "mlp_bf16_g2.hip"), os.path.join(CSRC, "mlp_bf16_g2e.hip"), os.path.join(CSRC, "api.hip"),
+                                  os.path.join(CSRC, "mfma_ceiling.hip"), "-o", DIAG_SO]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
