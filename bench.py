@@ -295,12 +295,12 @@ def image_tier(args, mlp, size="800x800"):
                "--no-cpu-baseline", "--no-bf16-tier", "--no-clock", "--mlp", mlp, "--image", size, "--steps", "5", "--warmup", "2"]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         d = json.loads(out.stdout.strip().splitlines()[-1])
+        im = d["image"]            # (a child line without it -- an error object, an older line format -- is an error HERE, not in the caller)
+        im["chunk_rays_per_s"] = d["value"]
+        im["image_over_chunk_rate"] = round(im["rays_per_s"] / d["value"], 4)
+        return im
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
-    im = d["image"]
-    im["chunk_rays_per_s"] = d["value"]
-    im["image_over_chunk_rate"] = round(im["rays_per_s"] / d["value"], 4)
-    return im
 
 
 def cpu_baseline(args, cfg, sd_c, sd_f, check_model=None):
@@ -438,6 +438,76 @@ def bf16_in_kernel_clock(flat_params, device, seconds=2.5):
             "warm_launches": n, "how": "diagnostic stamp build of the same kernel sources, random bf16 feature rows, after the timed region; "
             "frac ~= mfma_busy x in_kernel_clock / nominal_clock (less launch prologue / tail; the stamps themselves cost the diagnostic "
             "build a few per cent of busy share)"}
+
+
+def f32_in_kernel_clock(model, device, seconds=0.6):
+    """In-kernel clock of the HEADLINE kernel (the fp32 fine-MLP forward) and what its workgroups spend their cycles on, from the
+    diagnostic build of the same sources (-DF32_STAMP_TILE: every persistent workgroup stamps s_memtime / s_memrealtime at its first
+    and behind its last instruction), run back to back for `seconds` on the encoded fine pass of 4096 synthetic rays with this model's
+    weights, after the timed region.  Closes the roofline fraction of THAT run: frac = (algorithmic / issued FLOP) x (MFMA cycles /
+    workgroup cycles) x (workgroup time / launch time) x in-kernel clock / 2400."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from ddnerf_amd import build as hip_build
+    from ddnerf_amd import functions as F
+    from ddnerf_amd import ops, synthetic
+
+    if not os.path.exists(hip_build.DIAG_SO):
+        return None
+    L = C.CDLL(hip_build.DIAG_SO)
+    if not hasattr(L, "ddnerf_debug_f32_tile_stamps"):
+        return None
+    V = C.c_void_p
+    n, S = 4096, 128
+    M = n * S
+    st = torch.cuda.current_stream().cuda_stream
+    o, d, rad, _ = synthetic.make_rays("blender", n, 1)
+    rays = ops.pack_rays(*(torch.from_numpy(x).to(device) for x in (o, d, rad)), 2.0, 6.0)
+    t = (2.0 + 4.0 * torch.sort(torch.rand(n, S + 1, device=device), dim=1).values).contiguous()
+    feat = ops.encode(rays, t, kind="fp32")
+    packed = F._packed_weights(model.fine)         # (the product library's image: the diagnostic build reads the same format)
+    raw = torch.empty(M, 4, device=device)
+    f = L.ddnerf_mlp_f32_forward
+    f.argtypes = [V, V, C.c_int, V, C.c_long, V]
+    launch = lambda: f(feat.data_ptr(), packed.data_ptr(), 0, raw.data_ptr(), M, st)
+    t0, nl = time.time(), 0
+    while time.time() - t0 < seconds:
+        for _ in range(10):
+            launch()
+        torch.cuda.synchronize()
+        nl += 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    buf = np.zeros(4096 * 6, dtype=np.uint64)
+    if L.ddnerf_debug_f32_tile_stamps(C.c_void_p(buf.ctypes.data)):
+        return None
+    s = buf.reshape(4096, 6).astype(np.int64)
+    s = s[s[:, 2] > 0]                              # one row per persistent workgroup (the stamps of the LAST launch)
+    tiles_per_wg = (M // 128) / len(s)
+    dur = (s[:, 2] - s[:, 0]).astype(np.float64)
+    real = (s[:, 4] - s[:, 3]) / 100e6
+    clk = float(np.median(dur / real / 1e6))
+    kk = [96] * 8 + [256] * 32 + [352] * 8 + [256] * 24 + [288] * 5 + [128]          # K of every 32-row weight slice of the network
+    mfma_cycles = sum(32 * k for k in kk) * tiles_per_wg                            # k / 2 MFMAs of 64 cycles per slice and tile
+    mfma_share = float(mfma_cycles / np.median(dur))
+    wg_share = float(np.median(real) * 1e3 / ms)
+    issued_over_alg = sum(2 * 32 * k for k in kk) / FLOP_FINE                           # per sample: the padded rows / columns the tiles carry
+    frac = FLOP_FINE * M / (ms * 1e-3) / 1e12 / PEAK["fp32"]
+    pred = mfma_share * wg_share * clk / 2400.0 / issued_over_alg
+    return {"in_kernel_clock_mhz": round(clk), "nominal_clock_mhz": 2400, "mfma_share_of_workgroup_cycles": round(mfma_share, 4),
+            "workgroup_share_of_launch": round(wg_share, 4), "issued_over_algorithmic_flop": round(issued_over_alg, 4),
+            "back_to_back_launch_ms": round(ms, 4), "back_to_back_frac": round(frac, 4), "frac_from_the_stamps": round(pred, 4),
+            "closes_within": round(abs(pred / frac - 1.0), 4), "warm_launches": nl,
+            "how": "diagnostic stamp build (-DF32_STAMP_TILE) of the headline kernel's sources on the encoded fine pass of 4096 synthetic rays, "
+                   "after the timed region; frac_from_the_stamps = mfma_share x workgroup_share x clock / 2400 / issued_over_algorithmic"}
 
 
 def bf16_fused_in_kernel_clock(model, device, seconds=2.5):
@@ -664,6 +734,8 @@ def main(argv=None):
                     # (the launch that is timed also ENCODES its samples -- cast_rays + integrated_pos_enc, models/models.py:117-142 -- and
                     # the unfused path's encode launch is gone from the step; `achieved` / `frac` still count the MLP's FLOP only)
                     roof["kernel"] = "mlp_bf16g2e_fwd_kernel<fine> (encoder inside the MLP kernel; %d samples/launch)" % M_fine
+            if args.mlp == "fp32" and (args.rays, args.fine) == (4096, 128) and not args.no_clock and cfg.nerf.type == "DDNerfModel":
+                roof["clock"] = f32_in_kernel_clock(model, device)
             if args.mlp == "bf16" and (args.rays, args.fine) == (4096, 128) and not args.no_clock:
                 roof["clock"] = bf16_fused_in_kernel_clock(model, device) if fused else bf16_in_kernel_clock(model.fine.flat_params().detach(), device)
                 if fused:

@@ -92,8 +92,6 @@ _SIGS = {
     "ddnerf_composite_forward_keep_rng": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int] + [c_fp] * 7
                                           + [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, c_fp]),
     "ddnerf_dp_loss_forward_kept": (C.c_int, [c_fp] * 8 + [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
-    "ddnerf_dp_loss_ticket_blocks": (C.c_long, [C.c_int]),
-    "ddnerf_dp_loss_forward_kept1": (C.c_int, [c_fp] * 8 + [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_uint64, c_fp]),
     "ddnerf_mlp_f32_wgrad_workspace_floats": (C.c_size_t, [C.c_long]),
     "ddnerf_mlp_f32_wgrad": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, c_fp,
                                        C.c_int, C.c_int, c_fp, c_fp, c_fp]),

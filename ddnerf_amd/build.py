@@ -99,10 +99,12 @@ DIAG_SO = os.path.join(CSRC, "libddnerf_diag.so")
 
 def build_diag(force: bool = False, verbose: bool = False) -> str:
     deps = [os.path.join(CSRC, f) for f in ("mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "gen_bf16_g2.py", "mlp_mfma16.inc", "mlp_bf16_common.h",
-                                            "common.h", "api.hip", "mfma_ceiling.hip")] + [__file__]
+                                            "common.h", "api.hip", "mfma_ceiling.hip", "mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h")] + [__file__]
     if force or _stale(DIAG_SO, deps):
         generate(force, verbose)
-        cmd = [HIPCC] + COMMON + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_STAMP", "-DBF16_DISPATCH", "-shared", os.path.join(CSRC, "mlp_bf16.hip"),
+        # (-DF32_STAMP_TILE: the fp32 forward of the headline line with first / last-instruction stamps per workgroup, bench.py f32_in_kernel_clock)
+        cmd = [HIPCC] + COMMON + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_STAMP", "-DF32_STAMP_TILE", "-DBF16_DISPATCH", "-shared", os.path.join(CSRC, "mlp_f32.hip"),
+                                  os.path.join(CSRC, "mlp_bf16.hip"),
                                   os.path.join(CSRC, "mlp_bf16_g2.hip"), os.path.join(CSRC, "mlp_bf16_g2e.hip"), os.path.join(CSRC, "api.hip"),
                                   os.path.join(CSRC, "mfma_ceiling.hip"), "-o", DIAG_SO]
         if verbose:

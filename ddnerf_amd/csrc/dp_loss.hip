@@ -58,62 +58,11 @@ __global__ __launch_bounds__(256) void dpl_keep_kernel(const float *__restrict__
     if (live && lane == 0) keep[row] = blender ? (s > 1e-10f ? 1 : 0) : 1;
 }
 
-// exclusive scan of keep[0..n) by ONE 1024-thread block (n <= a few 10^4 rows per chunk)
-
-// The finish step inside the rows kernel (render path: one launch less): the workgroup that takes the LAST ticket of the launch adds up the
-// row sums -- by then every other workgroup has stored its rows' sums with agent-scope (sc1, write-through) stores, drained them
-// (s_waitcnt vmcnt(0) in every storing wave, then the workgroup's barrier) and added its ticket (one lane, agent-scope atomic); the
-// last workgroup acquires (agent scope) after its own add returns and reads the sums with sc1 loads.  The reduction reproduces
-// dpl_finish_kernel's arithmetic exactly: its 1024 "threads" are 4 per lane here, and the tree pairs the same partners in the same
-// order, so the loss is bit for bit the two-launch path's.  ticket: one 64-bit counter that only ever grows (every workgroup of every
-// launch adds 1); the host passes the value it had before the launch (it knows how many workgroups it has launched on it).
-struct DplFinish {
-    unsigned long long *ticket;
-    unsigned long long base;
-    float *loss;
-    const float *reg_scal;
-    float *loss_total;
-};
-
-__device__ __forceinline__ void dpl_finish_in_block(const float *__restrict__ rowsum, const int *__restrict__ keep, int n, int nf,
-                                                    float *__restrict__ loss, const float *__restrict__ reg_scal,
-                                                    float *__restrict__ loss_total) {
-    __shared__ double part[1024];
-    __shared__ int cnt[1024];
-    const int tid = threadIdx.x;   // 256 threads stand in for dpl_finish_kernel's 1024
-    for (int v = tid; v < 1024; v += 256) {
-        int c = 0;
-        for (int i = v; i < n; i += 1024) c += keep[i];
-        cnt[v] = c;
-    }
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        for (int v = tid; v < o; v += 256) cnt[v] += cnt[v + o];
-        __syncthreads();
-    }
-    const int R = cnt[0];  // kept rows
-    for (int v = tid; v < 1024; v += 256) {
-        double s = 0.0;
-        for (int r = v; r < R; r += 1024) s += (double)__hip_atomic_load(&rowsum[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (sc1 loads)
-        part[v] = s;
-    }
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        for (int v = tid; v < o; v += 256) part[v] += part[v + o];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const float l = R > 0 ? (float)(part[0] / ((double)R * nf)) : 0.0f;
-        *loss = l;
-        if (loss_total) *loss_total = (l * (float)nf + reg_scal[2]) + reg_scal[3];
-    }
-}
-
 __global__ __launch_bounds__(256) void dpl_rows_kernel(
     const float *__restrict__ t1, const float *__restrict__ t0, const float *__restrict__ w1,
     const float *__restrict__ w0, const float *__restrict__ mus0, const float *__restrict__ sig0,
     const float *__restrict__ left0, const float *__restrict__ part0, int n, int nc, int nf,
-    const int *__restrict__ keep, float *__restrict__ rowsum, DplFinish fin) {
+    const int *__restrict__ keep, float *__restrict__ rowsum) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * DPL_WAVES + wave;
@@ -192,32 +141,7 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
             acc += xlogy - p * logf(q);
         }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if (!fin.ticket) {
-        if (live && lane == 0) rowsum[r] = acc;
-        return;
-    }
-    // (see DplFinish) row sums leave through agent-scope stores; every storing wave drains them before the workgroup's one release
-    if (live && lane == 0) __hip_atomic_store(&rowsum[r], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __shared__ int is_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#ifdef DPL_RELEASE_FENCE   // (measured: an agent-scope release = an L2 write-back per workgroup, 1024 of them: the kernel 20 -> 39 us)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        // the row sums are the ONLY bytes handed over; they left as sc1 (write-through) stores that every storing wave has drained
-        // (s_waitcnt vmcnt(0) in front of the barrier above): nothing of them is left dirty in this XCD's L2 for a release to write back
-        const unsigned long long t = __hip_atomic_fetch_add(fin.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == fin.base + gridDim.x - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        is_last = last;
-    }
-    __syncthreads();
-    if (is_last) dpl_finish_in_block(rowsum, keep, n, nf, fin.loss, fin.reg_scal, fin.loss_total);
+    if (live && lane == 0) rowsum[r] = acc;
 }
 
 // mean over the kept rows in a fixed order (thread t owns rows t, t+1024, ...; then an LDS tree), and -- when the caller
@@ -271,7 +195,7 @@ DDN_EXPORT int ddnerf_dp_loss_forward(const float *t1, const float *t0, const fl
     size_t lds = (size_t)DPL_WAVES * (2 * nc + 3 * nf + 2) * sizeof(float);
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
     hipLaunchKernelGGL(dpl_rows_kernel, grid, dim3(256), lds, st, t1, t0, w1, w0, mus0, sig0, left0, part0, n, nc, nf,
-                       keep, rowsum, DplFinish{});
+                       keep, rowsum);
     hipLaunchKernelGGL(dpl_finish_kernel, dim3(1), dim3(1024), 0, st, rowsum, keep, n, nf, loss, reg_scal, loss_total);
     return ddn_launch_status();
 }
@@ -292,30 +216,8 @@ DDN_EXPORT int ddnerf_dp_loss_forward_kept(const float *t1, const float *t0, con
     size_t lds = (size_t)DPL_WAVES * (2 * nc + 3 * nf + 2) * sizeof(float);
     DDN_REQUIRE(lds <= 64 * 1024, DDNERF_E_RANGE);
     hipLaunchKernelGGL(dpl_rows_kernel, grid, dim3(256), lds, st, t1, t0, w1, w0, mus0, sig0, left0, part0, n, nc, nf,
-                       keep, rowsum, DplFinish{});
+                       keep, rowsum);
     hipLaunchKernelGGL(dpl_finish_kernel, dim3(1), dim3(1024), 0, st, rowsum, keep, n, nf, loss, reg_scal, loss_total);
-    return ddn_launch_status();
-}
-
-// ... in ONE launch: the workgroup that takes the launch's last ticket finishes (DplFinish above).  `ticket`: a device counter of 64 bits
-// that starts at 0 and is handed to nothing but this entry point; `ticket_base`: the number of workgroups launched on it so far =
-// the sum of ddnerf_dp_loss_ticket_blocks(n) over the earlier calls (all of them enqueued on one stream, or otherwise ordered).  Same
-// loss / loss_total bits as ddnerf_dp_loss_forward_kept.
-DDN_EXPORT long ddnerf_dp_loss_ticket_blocks(int n) { return n > 0 ? (long)((n + DPL_WAVES - 1) / DPL_WAVES) : 0; }
-DDN_EXPORT int ddnerf_dp_loss_forward_kept1(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,
-                                            const float *sig0, const float *left0, const float *part0, int n, int nc, int nf, float *loss,
-                                            const float *reg_scal, float *loss_total, void *workspace, unsigned long long *ticket,
-                                            unsigned long long ticket_base, ddnerf_stream_t stream) {
-    DDN_REQUIRE(t1 && t0 && w1 && w0 && mus0 && sig0 && left0 && part0 && loss && workspace && ticket, DDNERF_E_ARG);
-    DDN_REQUIRE((reg_scal == nullptr) == (loss_total == nullptr), DDNERF_E_ARG);
-    DDN_REQUIRE(n > 0 && nc > 0 && nf > 0, DDNERF_E_ARG);
-    int *keep = (int *)workspace;
-    float *rowsum = (float *)(keep + 2 * n);
-    dim3 grid((n + DPL_WAVES - 1) / DPL_WAVES);
-    size_t lds = (size_t)DPL_WAVES * (2 * nc + 3 * nf + 2) * sizeof(float);
-    DDN_REQUIRE(lds <= 48 * 1024, DDNERF_E_RANGE);   // (+ 12 KiB of static LDS for the in-block finish)
-    hipLaunchKernelGGL(dpl_rows_kernel, grid, dim3(256), lds, (hipStream_t)stream, t1, t0, w1, w0, mus0, sig0, left0, part0, n, nc, nf, keep,
-                       rowsum, DplFinish{ticket, ticket_base, loss, reg_scal, loss_total});
     return ddn_launch_status();
 }
 

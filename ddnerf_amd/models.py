@@ -123,7 +123,7 @@ class GeneralMipNerfModel(torch.nn.Module):
         """models/models.py:40-73"""
         shape_rgb = ray_directions.shape
         shape_depth = ray_directions.shape[:-1]
-        batches = self.get_rays_batches(ray_origins, ray_directions, ray_rad, mode, _defer=True)
+        batches = self._rays_batches(ray_origins, ray_directions, ray_rad, mode, defer=True)
         if rgb_target is not None:
             rgb_targets = get_minibatches(rgb_target.reshape(-1, 3), chunksize=getattr(self.cfg.nerf, mode).chunksize)
         else:
@@ -157,8 +157,15 @@ class GeneralMipNerfModel(torch.nn.Module):
                     output[i]["corrected_disp_map"] = output[i]["corrected_disp_map"].view(shape_depth)
         return output
 
-    def get_rays_batches(self, ray_origins, ray_directions, ray_rad, mode, _defer=False):
-        """models/models.py:144-162 (K0 pack kernel, then views of <= chunksize rays)"""
+    def get_rays_batches(self, ray_origins, ray_directions, ray_rad, mode):
+        """models/models.py:144-162 (K0 pack kernel, then views of <= chunksize rays).  The rows are filled when this returns."""
+        return self._rays_batches(ray_origins, ray_directions, ray_rad, mode, defer=False)
+
+    def _rays_batches(self, ray_origins, ray_directions, ray_rad, mode, defer):
+        """get_rays_batches; defer (run_iter ONLY): a one-chunk batch without jitter is handed out EMPTY and filled by the launch that
+        encodes its coarse samples -- predict's first step -- or, should anything come between (an exception included), by
+        run_iter's `finally: _flush_first_pending()`.  No public caller can obtain unfilled rows."""
+        _defer = defer
         self._t0_ready = None
         self._first_pending = None
         mc = self._mode_cfg(mode)

@@ -326,13 +326,17 @@ def _records_ticket(outs, host):
     """the event dd_records_finish waits for, recorded right behind the compaction"""
     ev = torch.cuda.Event()
     ev.record()
-    return outs, host, ev, host
+    return [outs, host, ev, host]     # (a list: dd_records_finish empties it -- a ticket is good for ONE finish)
 
 
 def dd_records_finish(ticket):
     """second half: wait for the length (the ONE host sync of a chunk, on an event recorded right behind the compaction) and
     slice the three records"""
+    if not ticket:
+        # finishing a ticket twice would hand its pinned length slot to the free list twice: two later launches would then share it
+        raise _lib.DDNerfHipError("dd_records_finish: this ticket has been finished already")
     outs, host, ev, _total = ticket
+    del ticket[:]
     ev.synchronize()
     k = int(host[0])
     _PINNED.setdefault(str(outs[0].device), []).append(host)
@@ -475,37 +479,19 @@ def composite_forward_keep(raw, t_vals, rays, noise, mus, white_bkgd, blender, d
     return o, ws
 
 
-_DP_TICKETS = {}   # (device, stream) -> [int64 counter tensor, workgroups launched on it so far]
-# (measured, round 4: the one-launch form is SLOWER -- 37.8 us against 20.2 + 4.9 us for the rows kernel and the finish kernel: 1024
-# workgroups take their tickets from ONE counter, ~88 atomics per microsecond, and the finish still runs behind the last of them --
-# so the two launches stay the default; profiles/r04_render_bf16_kernel_stats_dp_one_launch.csv)
-DP_ONE_LAUNCH = os.environ.get("DDNERF_DP_ONE_LAUNCH", "0") == "1"
-
-
 def dp_loss_forward_kept(t1, t0, w1, w0, mus0, sig0, left0, part0, ws, reg_scal):
     """dp_loss_forward behind composite_forward_keep (the row filter is in `ws` already) -> (loss, total [1]): the rows kernel and the
-    finish kernel.  DDNERF_DP_ONE_LAUNCH=1: ONE launch -- the workgroup that takes the launch's last ticket adds up the row sums
-    (ddnerf_dp_loss_forward_kept1; the counter lives per device and stream, where launches are ordered); same bits, measured slower."""
+    finish kernel.  (Round 4 built a ONE-launch form -- the workgroup taking the last of 1024 tickets finished -- and measured it SLOWER,
+    37.8 us against 20.2 + 4.9: one ticket counter takes ~88 atomics per microsecond; profiles/r04_render_bf16_kernel_stats_dp_one_launch.csv.
+    Round 5 removed it.)"""
     t1, t0, w1, w0, mus0, sig0, left0, part0 = (_f32c(t, "dp_loss arg") for t in (t1, t0, w1, w0, mus0, sig0, left0, part0))
     n, nc = w0.shape
     nf = w1.shape[1]
     loss = torch.empty((), dtype=torch.float32, device=w0.device)
     total = torch.empty(1, dtype=torch.float32, device=w0.device)
-    L = _lib.lib()
-    if not DP_ONE_LAUNCH:
-        _lib.check(L.ddnerf_dp_loss_forward_kept(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0), _ptr(part0),
-                                                 n, nc, nf, _ptr(loss), _ptr(_f32c(reg_scal, "reg_scal")), _ptr(total), _ptr(ws), _stream()),
-                   "ddnerf_dp_loss_forward_kept")
-        return loss, total
-    st = _stream()
-    key = (str(w0.device), st)
-    slot = _DP_TICKETS.get(key)
-    if slot is None:
-        slot = _DP_TICKETS[key] = [torch.zeros(1, dtype=torch.int64, device=w0.device), 0]
-    _lib.check(L.ddnerf_dp_loss_forward_kept1(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0), _ptr(part0),
-                                              n, nc, nf, _ptr(loss), _ptr(_f32c(reg_scal, "reg_scal")), _ptr(total), _ptr(ws), _ptr(slot[0]),
-                                              slot[1], st), "ddnerf_dp_loss_forward_kept1")
-    slot[1] += int(L.ddnerf_dp_loss_ticket_blocks(n))
+    _lib.check(_lib.lib().ddnerf_dp_loss_forward_kept(_ptr(t1), _ptr(t0), _ptr(w1), _ptr(w0), _ptr(mus0), _ptr(sig0), _ptr(left0), _ptr(part0),
+                                                      n, nc, nf, _ptr(loss), _ptr(_f32c(reg_scal, "reg_scal")), _ptr(total), _ptr(ws), _stream()),
+               "ddnerf_dp_loss_forward_kept")
     return loss, total
 
 
@@ -771,7 +757,11 @@ def ndc_depth_to_regular(ndc_depth, origins, directions):
 # weight-gradient arithmetic: "x3" = bf16 matrix cores with exact hi/lo operand splits (3 MFMAs per product, ~2^-16
 # relative product error, HBM-bound); "f32" = the fp32 matrix cores (exact fp32 products, MFMA-bound, 3x slower)
 # "x3p" = the same three-MFMA product on operands that already hold hi/lo words (what the x3 training kernels record)
+# DDNERF_WGRAD: "x3" (default) | "f32" | "pairs" (the fp32 tier's opt-in speed mode: its kernels record bf16 row pairs and the weight
+# gradients run the one-MFMA kernel "x3h").  Anything else is an error at import, not a KeyError in the first backward pass.
 WGRAD_MODE = os.environ.get("DDNERF_WGRAD", "x3")
+if WGRAD_MODE not in ("x3", "f32", "pairs"):
+    raise _lib.DDNerfHipError("DDNERF_WGRAD=%r: expected x3, f32 or pairs" % WGRAD_MODE)
 # "x3h" = ONE MFMA per product on records of bf16 row pairs (the x3 training tier: its forward / backward-data chains stay fp32-class,
 # the weight gradients contract bf16-rounded activations and deltas with fp32 accumulation -- half the record bytes, a third of the MFMAs)
 _WGRAD_FN = {"x3": "ddnerf_mlp_x3_wgrad", "f32": "ddnerf_mlp_f32_wgrad", "x3p": "ddnerf_mlp_x3_wgrad_packed", "x3h": "ddnerf_mlp_x3_wgrad_pairs"}
@@ -829,7 +819,7 @@ def x3_unsplit(rec):
 def mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, dst, dst_ld, dst_col0, dst_bias, workspace,
                       mode=None, max_wg=0):
     """dst[r*dst_ld + dst_col0 + c] = sum_s deltas[drow0+r][s] * acts[arow0+c][s]; dst_bias[r] = sum_s deltas[drow0+r][s]"""
-    mode = mode or WGRAD_MODE
+    mode = mode or {"pairs": "x3h"}.get(WGRAD_MODE, WGRAD_MODE)    # (a record-format name is not a kernel name)
     fn = getattr(_lib.lib(), _WGRAD_FN[mode])
     extra = (int(max_wg),) if mode in _RECORD_MODES else ()
     _lib.check(fn(_ptr(deltas), drow0, n_out, _ptr(acts), arow0, n_in, n_in_used, M, deltas.shape[1], _ptr(dst), dst_ld,

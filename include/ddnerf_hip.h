@@ -13,7 +13,12 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); work is enqueued on it
  *     and the caller keeps all buffers alive until the stream has passed them
  *   - random / linspace tensors (torch.rand, torch.randn, torch.linspace) are produced by the host
- *     framework and passed in, exactly like the reference draws them
+ *     framework and passed in, exactly like the reference draws them -- with ONE exception, a deliberate departure from
+ *     ddnerf_composite_forward_keep_rng / ddnerf_dd_coarse_sample_forward draw the density noise of
+ *     volume_rendering_utils.py:29-37 IN the kernel (Philox4x32-10 keyed by the seed and offset of torch's CUDA generator, which
+ *     the host advances as a torch random kernel would: reproducible under torch.manual_seed, but not torch.randn's values);
+ *     it saves a generator launch and a 3-MB tensor per pass on the render path.  A caller that needs the reference's exact
+ *     draws (the parity tests do) passes a noise tensor to ddnerf_composite_forward instead
  *   - return value: 0 = success; DDNERF_E_* (<0) = rejected arguments; >0 = hipError_t of the launch
  *   - the library is stateless (thread-safe); weights are passed per call
  *
@@ -319,16 +324,6 @@ int ddnerf_debug_philox_normal(float *out, long count, unsigned long long seed, 
 int ddnerf_dp_loss_forward_kept(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,
                                 const float *sig0, const float *left0, const float *part0, int n, int nc, int nf, float *loss,
                                 const float *reg_scal, float *loss_total, void *workspace, ddnerf_stream_t stream);
-/* ... in ONE launch: the workgroup that takes the launch's last ticket adds up the row sums (bit for bit ddnerf_dp_loss_forward_kept's
- * loss / loss_total).  ticket: a 64-bit device counter that starts at 0 and is handed to nothing but this entry point; ticket_base: the
- * number of workgroups launched on it so far = the sum of ddnerf_dp_loss_ticket_blocks(n) over the earlier calls (all ordered before this
- * one, e.g. enqueued on the same stream). */
-long ddnerf_dp_loss_ticket_blocks(int n);
-int ddnerf_dp_loss_forward_kept1(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0, const float *sig0,
-                                 const float *left0, const float *part0, int n, int nc, int nf, float *loss, const float *reg_scal,
-                                 float *loss_total, void *workspace, unsigned long long *ticket, unsigned long long ticket_base,
-                                 ddnerf_stream_t stream);
-
 /* backward of estimate_dp_loss w.r.t. (w0, mus0, sig0); g_loss[0] = upstream gradient of the scalar loss.
  * workspace as for the forward. */
 int ddnerf_dp_loss_backward(const float *t1, const float *t0, const float *w1, const float *w0, const float *mus0,

@@ -108,3 +108,30 @@ def test_packed_weight_cache_follows_parameter_updates():
         net.flat_params().add_(1.0)          # direct write (what a broadcast does) needs the explicit invalidation
     net.invalidate_packed()
     assert F._cached_pack(net, "x", builder) == 4 and calls[3] == float(net.flat_params().numel())
+
+
+def test_the_frozen_fork_of_the_16_bit_mfma_body_has_not_drifted():
+    """mlp_mfma16_hilo.inc is a frozen fork of mlp_mfma16.inc (the x3 tier's strict mode, DDNERF_X3_WGRAD=exact: records of hi/lo words
+    instead of bf16 row pairs).  A fix to the shared body has to be made in BOTH files or the strict mode silently diverges: this test
+    pins the set of lines in which the two files differ (tests/golden/mfma16_fork.diff).  When it fails, either port the change to the
+    other file, or -- if the difference is a deliberate, record-format-specific one -- regenerate the pinned diff (the command is in the
+    assertion message) and say so in the commit."""
+    got = _fork_diff()
+    want = [ln.rstrip("\n") for ln in open(os.path.join(ROOT, "tests", "golden", "mfma16_fork.diff"))]
+    want = [ln[:2] + ln[2:].strip() for ln in want]
+    assert sorted(got) == sorted(want), ("the two forks' differences changed: %d lines now, %d pinned; port the change, or regenerate with "
+                                         "`python tests/test_abi.py --pin-fork-diff`" % (len(got), len(want)))
+
+
+def _fork_diff():
+    import difflib
+
+    csrc = os.path.join(ROOT, "ddnerf_amd", "csrc")
+    a = [ln.rstrip() for ln in open(os.path.join(csrc, "mlp_mfma16.inc"))]
+    b = [ln.rstrip() for ln in open(os.path.join(csrc, "mlp_mfma16_hilo.inc"))]
+    return [("< " if ln[0] == "-" else "> ") + ln[1:].strip() for ln in difflib.unified_diff(a, b, lineterm="", n=0)
+            if ln[:1] in "+-" and not ln.startswith(("+++", "---"))]
+
+
+if __name__ == "__main__" and "--pin-fork-diff" in __import__("sys").argv:
+    open(os.path.join(ROOT, "tests", "golden", "mfma16_fork.diff"), "w").write("\n".join(_fork_diff()) + "\n")

@@ -128,3 +128,14 @@ def test_two_ranks_under_torch_distributed_run_on_one_gpu():
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["global_rays"] == 2048 and d["train"]["value"] > 0
+
+
+def test_config_360_strong_scaling_command_line_on_one_gpu():
+    """BASELINE configs[3] -- config_360.yml, 8192 rays split over the ranks (--global-rays: strong scaling), data-parallel with the
+    gradient all-reduce -- as two supervised ranks sharing the box's one GPU over gloo: the first real 8-GPU run of that configuration
+    must not be the first execution of this argument path (round-4 review, item 9)."""
+    d = _bench("--gpus", "2", "--global-rays", "8192", "--config", "config_360.yml", "--backend", "gloo", "--share-gpu")
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["global_rays"] == 8192 and d["config"]["rays_per_gpu"] == 4096 and "config_360.yml" in d["config"]["workload"]
+    assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert d["train"]["value"] > 0 and "all-reduce" in d["train"]["collective"]
