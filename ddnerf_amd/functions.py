@@ -148,6 +148,7 @@ class _DDHeadFunction(torch.autograd.Function):
         d = ops.dd_head(raw6, smooth, dist_reg)
         ctx.save_for_backward(raw6)
         ctx.dist_reg = float(dist_reg)
+        ctx.set_materialize_grads(False)      # (an output nobody differentiates arrives as None, not as a zero-filled tensor: the kernel takes NULL)
         outs = (d["mus"], d["sigmas"], d["left"], d["part"], d["ssig"], d["sleft"], d["spart"], d["scal"])
         ctx.mark_non_differentiable(*outs[2:7])
         return outs
@@ -155,6 +156,8 @@ class _DDHeadFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_mus, g_sigmas, _gl, _gp, _gss, _gsl, _gsp, g_scal):
         (raw6,) = ctx.saved_tensors
+        if g_mus is None and g_sigmas is None and g_scal is None:
+            return None, None, None
         g_raw6 = torch.zeros_like(raw6)
         ops.dd_head_backward_(raw6, ctx.dist_reg, g_mus, g_sigmas, g_scal, g_raw6)
         return g_raw6, None, None
@@ -174,6 +177,7 @@ class _CompositeFunction(torch.autograd.Function):
         c = ops.composite_forward(raw, t_vals, rays, noise, mus, white_bkgd, blender)
         ctx.save_for_backward(raw, t_vals, rays, noise)
         ctx.flags = (bool(white_bkgd), bool(blender))
+        ctx.set_materialize_grads(False)      # (the fine pass's weights carry no gradient: None instead of a zero-filled [n,S] tensor)
         ctx.has_cdisp = c["cdisp"] is not None
         nd = [c["disp"], c["acc"], c["depth"]] + ([c["cdisp"]] if ctx.has_cdisp else [])
         ctx.mark_non_differentiable(*nd)
@@ -184,6 +188,8 @@ class _CompositeFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb_map, g_weights, *_unused):
         raw, t_vals, rays, noise = ctx.saved_tensors
+        if g_rgb_map is None and g_weights is None:
+            return None, None, None, None, None, None, None
         if g_rgb_map is None:
             g_rgb_map = torch.zeros((raw.shape[0], 3), dtype=torch.float32, device=raw.device)
         g_raw = ops.composite_backward(raw, t_vals, rays, noise, ctx.flags[0], ctx.flags[1], g_rgb_map, g_weights)

@@ -41,7 +41,9 @@ class TrainStepper:
                 gp["lr"] = lr
         out = model.run_iter(ray_origins, ray_directions, ray_rad, mode="train", rgb_target=target)
         losses = [torch.nn.functional.mse_loss(out[j]["rgb"], target) for j in range(len(out))]
-        loss = sum(cfg.train_params.loss_coeficients[j] * losses[j] for j in range(len(out)))  # :159-161
+        loss = cfg.train_params.loss_coeficients[0] * losses[0]                                # :159-161 (no `0 +` launch in front)
+        for j in range(1, len(out)):
+            loss = loss + cfg.train_params.loss_coeficients[j] * losses[j]
         if self.dd:
             dp = out[1]["dp_loss"].mean()                                                      # :163-167
             loss = loss + cfg.train_params.dp_coeficient * dp

@@ -167,20 +167,41 @@ def test_training_curve_tracks_the_reference(name, mlp_dtype, monkeypatch):
     assert np.all(np.abs(got_loss - ref_loss) <= 0.005 * np.abs(ref_loss) + 1e-5)
 
 
+def _reference_self_distance():
+    """How far the REFERENCE drifts from ITSELF over the 1500 iterations of train1500_dd_blender under a perturbation of fp32 round-off
+    size (tests/golden/train1500_drift_dd_blender.npz, make_golden.py gen_drift1500: every initial weight moved one ulp; the same
+    arithmetic on 4 ATen threads instead of 8), in the metrics of the test below: the larger of the two perturbations' distances.
+    Round 5: max |d PSNR| 0.60 / 0.63 dB (both at record 43 = iteration 1075, where the HIP tiers' maxima sit too), mean 0.087 / 0.088,
+    mean of the last six records 0.004 / 0.046, relative loss 6.0 / 5.3 %."""
+    g, d = _load("train1500_dd_blender"), _load("train1500_drift_dd_blender")
+    out = dict(max=0.0, mean=0.0, last6=0.0, loss=0.0)
+    for tag in ("ulp", "thr4"):
+        dp = np.abs(_psnr(d["mse_" + tag]) - _psnr(g["mse"]))
+        out["max"] = max(out["max"], float(dp.max()))
+        out["mean"] = max(out["mean"], float(dp.mean()))
+        out["last6"] = max(out["last6"], float(abs(_psnr(d["mse_" + tag][-6:, 1]).mean() - _psnr(g["mse"][-6:, 1]).mean())))
+        out["loss"] = max(out["loss"], float(np.max(np.abs(d["loss_" + tag] - g["loss"]) / np.abs(g["loss"]))))
+    return out
+
+
 @pytest.mark.parametrize("mlp_dtype", ["fp32", "x3", "x3-exact"])
 def test_training_curve_1500_iterations_of_the_real_schedule(mlp_dtype, monkeypatch):
     """The FIRST 1500 steps of a real run: the schedule train_model.py hard-wires (:101-107 -- 5e-4 -> 5e-6 over the config's
     train_iters with the 2500-step x0.01 warm-up), DDNerfModel, 256 fresh rays per iteration, loss / PSNR every 25 iterations against
     the reference loop's (tests/golden/train1500_dd_blender.npz, make_golden.py gen_train1500): PSNR 11.9 -> 29.8 dB.  Two fp32-class
-    implementations of one chaotic optimisation drift apart slowly: measured in round 4 (tools/train_curve_stats.py) -- max |d PSNR| at any
-    recorded iteration 0.47 dB (fp32 tier) / 0.66 (x3) / 0.72 (x3, exact records), all three at iteration 1075; mean over the records
-    0.07 - 0.09 dB; mean of the last 150 iterations within 0.009 dB; losses within 4 - 6 %.  Held to 1.0 dB / 0.15 dB / 0.1 dB / 10 %."""
+    implementations of one chaotic optimisation drift apart slowly -- and so does the reference from itself: the bars are 1.25 x the
+    REFERENCE-vs-REFERENCE distance under a perturbation of round-off size (_reference_self_distance: 0.79 dB max / 0.11 dB mean /
+    0.058 dB on the last six records / 7.5 % of the loss), not chosen.  Measured (tools/train_curve_stats.py): max |d PSNR| 0.47 dB
+    (fp32 tier: LESS than the reference's own 0.60 - 0.63) / 0.66 (x3) / 0.72 (x3, exact records), all at iteration 1075 like the
+    reference's; mean 0.07 - 0.09 dB; last six records within 0.009 dB; losses within 4 - 6 %."""
     got_loss, got_mse, g = _training_curve("train1500_dd_blender", mlp_dtype, monkeypatch)
     ref_loss, ref_mse = g["loss"], g["mse"]
+    bar = {k: 1.25 * v for k, v in _reference_self_distance().items()}
+    assert 0.5 <= bar["max"] <= 1.0 and 0.05 <= bar["mean"] <= 0.15, bar     # (the calibration itself: a fixture that no longer drifts would make the bars vacuous)
     assert ref_mse[-1, 1] < 0.05 * ref_mse[0, 1]                       # the reference run learns: 18 dB in these 1500 steps
     assert abs(got_loss[0] - ref_loss[0]) <= 2e-5 * max(1.0, abs(ref_loss[0]))
     d_psnr = np.abs(_psnr(got_mse) - _psnr(ref_mse))
-    assert d_psnr.max() <= 1.0, (d_psnr.max(), int(d_psnr.argmax()))
-    assert d_psnr.mean() <= 0.15, d_psnr.mean()
-    assert abs(_psnr(got_mse[-6:, 1]).mean() - _psnr(ref_mse[-6:, 1]).mean()) <= 0.1
-    assert np.all(np.abs(got_loss - ref_loss) <= 0.10 * np.abs(ref_loss) + 1e-5)
+    assert d_psnr.max() <= bar["max"], (d_psnr.max(), int(d_psnr.argmax()), bar)
+    assert d_psnr.mean() <= bar["mean"], (d_psnr.mean(), bar)
+    assert abs(_psnr(got_mse[-6:, 1]).mean() - _psnr(ref_mse[-6:, 1]).mean()) <= bar["last6"], bar
+    assert np.all(np.abs(got_loss - ref_loss) <= bar["loss"] * np.abs(ref_loss) + 1e-5), (float(np.max(np.abs(got_loss - ref_loss) / np.abs(ref_loss))), bar)

@@ -1,10 +1,11 @@
 """gpurun_out/refresh/* (tools/refresh_profiles.sh) -> profiles/<round>_* (round: argv[1], default r02)"""
 import os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 O = os.path.join(R, "gpurun_out", "refresh")
 P = os.path.join(R, "profiles")
-pairs = [("bench_fp32.json", "render_fp32_bench.json"), ("bench_bf16.json", "render_bf16_bench.json"), ("bench_x3.json", "render_x3_bench.json"), ("bench_fp16.json", "render_fp16_bench.json"), ("p_fp16/r_kernel_stats.csv", "render_fp16_kernel_stats.csv"),
+pairs = [("bench_fp32.json", "render_fp32_bench.json"), ("bench_bf16.json", "render_bf16_bench.json"), ("bench_bf16_unfused.json", "render_bf16_unfused_bench.json"),
+         ("p_bf16u/r_kernel_stats.csv", "render_bf16_unfused_kernel_stats.csv"), ("bench_x3.json", "render_x3_bench.json"), ("bench_fp16.json", "render_fp16_bench.json"), ("p_fp16/r_kernel_stats.csv", "render_fp16_kernel_stats.csv"),
          ("bench_train_fp32.json", "train_fp32_bench.json"), ("bench_train_x3.json", "train_x3_bench.json"),
          ("bench_config_ff.yml.json", "render_config_ff_bench.json"), ("bench_config_360.yml.json", "render_config_360_bench.json"),
          ("bench_config_blender_mipnerf.yml.json", "render_config_blender_mipnerf_bench.json"),
