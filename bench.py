@@ -510,6 +510,46 @@ def f32_in_kernel_clock(model, device, seconds=0.6):
                    "after the timed region; frac_from_the_stamps = mfma_share x workgroup_share x clock / 2400 / issued_over_algorithmic"}
 
 
+def bf16_unfused_mlp_launch(model, device, rays=4096, S=128, launches=200):
+    """The SAME fine MLP as a launch of its own (ddnerf_mlp_bf16_forward on rows ddnerf_encode wrote): what `roofline.frac` was before the
+    encoder moved into the kernel, measured in this run on this device -- the timed step's launch also encodes, so its `frac` (MLP FLOP /
+    launch time) is not comparable with earlier rounds' without this figure beside it.  After the timed region, back to back."""
+    import torch
+
+    from ddnerf_amd import functions as F
+    from ddnerf_amd import ops, synthetic
+
+    o, d, rad, _ = synthetic.make_rays("blender", rays, 1)
+    packed_rays = ops.pack_rays(*(torch.from_numpy(x).to(device) for x in (o, d, rad)), 2.0, 6.0)
+    t = (2.0 + 4.0 * torch.sort(torch.rand(rays, S + 1, device=device), dim=1).values).contiguous()
+    feat = ops.encode(packed_rays, t, kind="bf16")
+    packed = F._packed_weights(model.fine)
+    hook, ops.MLP_LAUNCH_HOOK = ops.MLP_LAUNCH_HOOK, None
+    try:
+        for _ in range(launches):
+            ops.mlp_bf16_forward(feat, packed, False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            ops.mlp_bf16_forward(feat, packed, False)
+        e1.record()
+        torch.cuda.synchronize()
+        enc0, enc1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        enc0.record()
+        for _ in range(launches):
+            ops.encode(packed_rays, t, kind="bf16")
+        enc1.record()
+        torch.cuda.synchronize()
+    finally:
+        ops.MLP_LAUNCH_HOOK = hook
+    ms = e0.elapsed_time(e1) / launches
+    M = rays * S
+    return {"kernel": "mlp_bf16g2_fwd_kernel<fine> on the rows of ddnerf_encode (%d samples/launch)" % M, "launch_ms": round(ms, 4),
+            "frac": round(FLOP_FINE * M / (ms * 1e-3) / 1e12 / PEAK["bf16"], 4), "encode_launch_ms": round(enc0.elapsed_time(enc1) / launches, 4),
+            "launches_timed": launches, "how": "back to back after the timed region, HIP events around %d launches" % launches}
+
+
 def bf16_fused_in_kernel_clock(model, device, seconds=2.5):
     """As bf16_in_kernel_clock for the FUSED kernel the bf16 render step runs (mlp_bf16_g2e.hip: the encoder inside the MLP kernel):
     the diagnostic build of the same sources back to back on a fine pass of 4096 synthetic rays x 128 sorted fenceposts; its tile
@@ -740,6 +780,7 @@ def main(argv=None):
                 roof["clock"] = bf16_fused_in_kernel_clock(model, device) if fused else bf16_in_kernel_clock(model.fine.flat_params().detach(), device)
                 if fused:
                     roof["clock_unfused_mlp"] = bf16_in_kernel_clock(model.fine.flat_params().detach(), device, seconds=1.5)
+                    roof["unfused_mlp_launch"] = bf16_unfused_mlp_launch(model, device)
                 roof["ceiling_same_box"] = bf16_same_box_ceiling(device, roof["frac"])
         elif head == "train":
             roof = train_roofline(args, cfg, dt / args.steps)

@@ -56,6 +56,14 @@ def test_render_line_has_the_contract_fields():
     assert 0.5 < ceil["lds_fed_staged"]["frac"] <= ceil["lds_fed"]["frac"] + 0.03 and ceil["lds_fed"]["frac"] <= ceil["registers"]["frac"] + 0.03 < 1.03
     assert abs(ceil["kernel_frac_over_staged_ceiling"] - d["bf16_tier"]["roofline"]["frac"] / ceil["lds_fed_staged"]["frac"]) < 2e-3
     assert d["roofline"]["traffic_measured_in_run"] is False
+    # round 5: the headline line proves its own fraction from in-kernel clock stamps; the bf16 step runs the fused encoder + MLP kernel and
+    # carries the same MLP as a launch of its own beside it
+    hc = d["roofline"]["clock"]
+    assert 2000 < hc["in_kernel_clock_mhz"] <= 2500 and 0.9 < hc["mfma_share_of_workgroup_cycles"] <= 1.0 and hc["closes_within"] < 0.02, hc
+    br = d["bf16_tier"]["roofline"]
+    assert br["encoder_in_kernel"] is True and "g2e" in br["kernel"] and "encoder inside" in clk["kernel"]
+    um = br["unfused_mlp_launch"]
+    assert 0.3 < um["frac"] < 1.0 and um["launch_ms"] > 0 and um["encode_launch_ms"] > 0 and um["launch_ms"] + um["encode_launch_ms"] > br["launch_ms"]
     for tier in ("fp32", "fp16", "bf16"):
         im = d["image"][tier]
         assert im["size"] == "800x800" and im["chunks"] == 40 and im["rays_per_s"] > 0 and 0.9 <= im["image_over_chunk_rate"] <= 1.1, (tier, im)
