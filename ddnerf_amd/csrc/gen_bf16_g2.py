@@ -152,7 +152,9 @@ S_ST = 76                                                            # soffset o
 S_GC = 93                                                            # group index of this tile's first group
 # asm operands of the fused body: %0 scratch rows of this workgroup (buffer resource)  %1 outputs  %2 %3 weight image  %4 LDS base  %5 wave
 #   %6 tile  %7 grid  %8 first tile  %9 t_vals (buffer resource)  %10 ray table (buffer resource)  %11 S + 1  %12 ceil(2^31 / (S / 64))
-#   %13 n - 1  %14 S / 64  %15 ray table (64-bit address)
+#   %13 n - 1  %14 S / 64  %15 ray table (64-bit address)  %16 the scratch rows as the encoder's STORES see them: operand %0, or -- in a
+#   workgroup's last tile, whose "next tile" does not exist -- a zero-length copy of it (the bounds check drops the stores: 25 MB per
+#   launch that nobody would read)
 
 
 def lit(x):
@@ -575,7 +577,7 @@ class Gen:
                     if half == 1:
                         m = col // 4
                         for pair, piece in ((ps, m), (pc, 12 + m)):
-                            ops.append(("store", "s_add_u32 s%d, s%d, %d\n\tbuffer_store_dwordx2 v[%d:%d], %s, %%0, s%d offen"
+                            ops.append(("store", "s_add_u32 s%d, s%d, %d\n\tbuffer_store_dwordx2 v[%d:%d], %s, %%16, s%d offen"
                                         % (S_ST, S_GB + g, piece * 512, pair, pair + 1, v(vrow), S_ST), pair))
             return ops
         # 24 column pairs: pair i = columns (2 i, 2 i + 1) of the sine block and of the cosine block; i = 3 j + r: octave pair j, slot r
@@ -613,7 +615,7 @@ class Gen:
             if half == 1:
                 m = i // 2
                 for pair, piece in ((ps, m), (pc, 12 + m)):
-                    ops.append(("store", "s_add_u32 s%d, s%d, %d\n\tbuffer_store_dwordx2 v[%d:%d], %s, %%0, s%d offen"
+                    ops.append(("store", "s_add_u32 s%d, s%d, %d\n\tbuffer_store_dwordx2 v[%d:%d], %s, %%16, s%d offen"
                                 % (S_ST, S_GB + g, piece * 512, pair, pair + 1, v(vrow), S_ST), pair))
         return ops
 
@@ -1119,7 +1121,7 @@ class Gen:
                         e("s_waitcnt vmcnt(%d)" % min(63, self.pro_ndma + (2 if g == 0 else 0)))
                     elif op[0] == "sload" or (op[0] == "i" and (ENC_PROLOGUE or not op[1].startswith("v_"))) or (op[0] == "store" and ENC_PROLOGUE):
                         for ln in op[1].split("\n\t"):
-                            e(ln)
+                            e(ln.replace("%16", "%0"))       # (THIS tile's rows: always stored, also when the first tile is the last one)
             # (a wave's store and its later load of the same address stay in order in the memory pipeline: no wait between them)
         for c in range(4):
             for q in range(3):

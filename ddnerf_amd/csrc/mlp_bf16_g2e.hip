@@ -57,19 +57,21 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
 #endif
 #pragma clang loop unroll(disable)
     for (unsigned tile = tile0; tile < (unsigned)a.ntiles; tile += grid) {
+        // (the encoder's stores: this workgroup's scratch, or nothing when there is no next tile to encode for)
+        const u32x4 sst = {srs.x, srs.y, (unsigned long)tile + grid < (unsigned long)a.ntiles ? srs.z : 0u, srs.w};
         if constexpr (DEPTH_HEAD) {
             asm volatile(
 #include "mlp_bf16_g2e_body_d1.gen.inc"
                 :
                 : "s"(srs), "s"(rrs), "s"(plo), "s"(phi), "s"(lds0), "s"(wave), "s"(tile), "s"(grid), "s"(tile0), "s"(trs), "s"(yrs), "s"(s1),
-                  "s"(magic), "s"(nmax), "s"(d64), "s"(tab)
+                  "s"(magic), "s"(nmax), "s"(d64), "s"(tab), "s"(sst)
                 : G2E_CLOBBERS);
         } else {
             asm volatile(
 #include "mlp_bf16_g2e_body_d0.gen.inc"
                 :
                 : "s"(srs), "s"(rrs), "s"(plo), "s"(phi), "s"(lds0), "s"(wave), "s"(tile), "s"(grid), "s"(tile0), "s"(trs), "s"(yrs), "s"(s1),
-                  "s"(magic), "s"(nmax), "s"(d64), "s"(tab)
+                  "s"(magic), "s"(nmax), "s"(d64), "s"(tab), "s"(sst)
                 : G2E_CLOBBERS);
         }
 #ifdef BF16_STAMP

@@ -88,15 +88,16 @@ def test_operand_ranges_and_counts(gen, body):
     assert n_store == (16 if depth_head else 8)                              # the outputs
     assert sum(1 for t in lines if t.startswith("buffer_store")) == n_store + (96 if fused else 0)
     if fused:
-        enc = [t for t in lines if t.startswith("buffer_store_dwordx2") and "%0" in t]
+        enc = [t for t in lines if t.startswith("buffer_store_dwordx2") and ("%16" in t or "%0" in t)]
         # the encoder: 2 groups x 24 four-column pieces per tile, and the same once more in the first tile's prologue; every piece of a
         # group's area ([piece][sample][8 bytes]) exactly once per group, the store's soffset set by the instruction in front of it
         assert len(enc) == 96
         start = lines.index(".Lsteady%=:") + 1
-        for part in (lines[:start], lines[start:]):
+        # (the first tile's own rows go to the scratch operand %0; the NEXT tile's through %16, which the shell empties in a workgroup's last tile)
+        for part, res in ((lines[:start], "%0,"), (lines[start:], "%16,")):
             offs = {}
             for a, b in zip(part, part[1:]):
-                if b.startswith("buffer_store_dwordx2") and "%0" in b:
+                if b.startswith("buffer_store_dwordx2") and res in b:
                     m = re.fullmatch(r"s_add_u32 s76, (s4[67]), (\d+)", a)
                     assert m and b.split(",")[3].split()[0] == "s76" and "offset" not in b, (a, b)
                     offs.setdefault(m.group(1), []).append(int(m.group(2)))

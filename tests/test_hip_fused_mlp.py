@@ -107,3 +107,39 @@ def test_fused_kernel_launch_after_launch(ops):
         want = ops.mlp_bf16_forward(ops.encode(rays, t, kind="bf16"), packed, True)
         torch.cuda.synchronize()
         _assert_same(got, want, it)
+
+
+@pytest.mark.parametrize("name", ["fullsize_cfg2_dd_blender_4096_64x128", "fullsize_cfg3_dd_llff_4096_64x128", "fullsize_trained_dd_blender_4096_64x128"])
+def test_run_iter_is_the_same_with_the_encoder_inside_or_outside_the_mlp_kernel(name, monkeypatch):
+    """The whole render pass of the bf16 tier at BASELINE size: DDNERF_FUSE_ENCODER = all (default: both passes one launch each), fine (the
+    coarse pass keeps its encode launch) and 0 (two launches per pass) give the SAME output dict, bit for bit -- the kernels are bit-identical, so
+    every downstream value (sampler, compositing, dp loss, records) is too.  Also as an image of several chunks (the per-chunk ray table)."""
+    from _cases import load_fullsize
+    from ddnerf_amd import models as M
+    from test_hip_run_iter import build_model
+
+    c = load_fullsize(name)
+    ro, rd, rad, tgt = (torch.from_numpy(x).cuda() for x in synthetic.make_rays(c["kind"], c["n"], 1))
+
+    def run(mode, chunk=None):
+        monkeypatch.setattr(M, "FUSE_ENCODER", mode)
+        model = build_model(c)
+        model.cfg.nerf["mlp_dtype"] = "bf16"
+        model._set_mlp_dtype()
+        model.eval()
+        if chunk:
+            model.cfg.nerf.validation["chunksize"] = chunk
+        with torch.no_grad():
+            return model.run_iter(ro, rd, rad, mode="validation", rgb_target=tgt)
+
+    ref = run("0")
+    for mode, chunk in (("all", None), ("fine", None), ("all", 1024)):
+        out = run(mode, chunk)
+        assert out.keys() == ref.keys()
+        for lvl in ref:
+            for k, v in ref[lvl].items():
+                if v is None or v is False or chunk and k in ("dp_loss", "mus_reg", "sig_reg", "mus_loss", "sig_loss", "mus", "sigmas", "smoothed_sigmas"):
+                    continue          # (per-chunk scalars and records have another shape when the batch is split)
+                w = out[lvl][k]
+                assert w.shape == v.shape, (mode, chunk, lvl, k)
+                assert torch.equal(torch.nan_to_num(w), torch.nan_to_num(v)), (mode, chunk, lvl, k)
