@@ -31,6 +31,8 @@ _SIGS = {
     "ddnerf_mlp_bf16g2_packed_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_bf16g2_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_bf16g2_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
+    "ddnerf_train_loss_forward": (C.c_int, [c_fp, c_fp, c_fp, C.c_long, c_fp, C.c_int, C.c_float, C.c_float, C.c_float, c_fp, c_fp]),
+    "ddnerf_train_loss_backward": (C.c_int, [c_fp, c_fp, c_fp, C.c_long, C.c_int, C.c_float, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_ray_table_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_ray_table": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_pack_rays_first_cycle_table": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),

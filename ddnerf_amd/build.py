@@ -20,6 +20,7 @@ SOURCES = {
     "samplers.hip": EXACT,
     "dp_loss.hip": EXACT,
     "raygen.hip": EXACT,
+    "train_loss.hip": EXACT,
     "mlp_f32.hip": [],
     "mlp_f32_train.hip": [],
     "mlp_f32_train_rec.hip": [],

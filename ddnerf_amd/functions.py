@@ -226,3 +226,31 @@ def dp_loss(t1, t0, w1, w0, mus0, sig0, left0, part0, blender):
     if torch.is_grad_enabled() and (w0.requires_grad or mus0.requires_grad or sig0.requires_grad):
         return _DPLossFunction.apply(w0, mus0, sig0, t1, t0, w1, left0, part0, blender)
     return ops.dp_loss_forward(t1, t0, w1, w0, mus0, sig0, left0, part0, blender)
+
+
+# ---- the training loss -------------------------------------------------------------------------------------
+class _TrainLossFunction(torch.autograd.Function):
+    """train_model.py:156-172: c0 mse(rgb_coarse, target) + c1 mse(rgb_fine, target) + c_dp mean(dp_loss) as ONE launch, its gradient as one
+    (ops.train_loss_forward / _backward; the torch op chain it replaces was ~26 small launches per step)"""
+
+    @staticmethod
+    def forward(ctx, rgb0, rgb1, target, dp, c0, c1, c_dp):
+        out = ops.train_loss_forward(rgb0, rgb1, target, dp, c0, c1, c_dp)
+        ctx.save_for_backward(rgb0, rgb1, target)
+        ctx.coef = (float(c0), float(c1), float(c_dp))
+        ctx.n_dp = 0 if dp is None else dp.numel()
+        ctx.dp_shape = None if dp is None else dp.shape
+        parts = out[1:]
+        ctx.mark_non_differentiable(parts)
+        return out[0], parts
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        rgb0, rgb1, target = ctx.saved_tensors
+        g0, g1, gd = ops.train_loss_backward(rgb0, rgb1, target, ctx.n_dp, *ctx.coef, g.reshape(1))
+        return g0.view_as(rgb0), None if g1 is None else g1.view_as(rgb1), None, None if gd is None else gd.view(ctx.dp_shape), None, None, None
+
+
+def train_loss(rgb0, rgb1, target, dp, c0, c1, c_dp):
+    """-> (loss [0-dim, differentiable w.r.t. rgb0, rgb1, dp], parts [3] = (mse0, mse1, mean dp), detached)"""
+    return _TrainLossFunction.apply(rgb0, rgb1, target, dp, float(c0), float(c1), float(c_dp))

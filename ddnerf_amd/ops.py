@@ -149,6 +149,25 @@ def _bf16_variant_forward(which, feat, packed, depth_head):
     return raw
 
 
+def train_loss_forward(rgb0, rgb1, target, dp, c0, c1, c_dp):
+    """train_model.py:156-172 in one launch -> out [4] = (loss, mse0, mse1, mean dp)"""
+    rgb0, rgb1, target, dp = _f32c(rgb0, "rgb0"), _f32c(rgb1, "rgb1"), _f32c(target, "target"), _f32c(dp, "dp")
+    out = torch.empty(4, dtype=torch.float32, device=rgb0.device)
+    _lib.check(_lib.lib().ddnerf_train_loss_forward(_ptr(rgb0), _ptr(rgb1), _ptr(target), rgb0.numel(), _ptr(dp), 0 if dp is None else dp.numel(),
+                                                    float(c0), float(c1), float(c_dp), _ptr(out), _stream()), "ddnerf_train_loss_forward")
+    return out
+
+
+def train_loss_backward(rgb0, rgb1, target, n_dp, c0, c1, c_dp, g):
+    rgb0, rgb1, target, g = _f32c(rgb0, "rgb0"), _f32c(rgb1, "rgb1"), _f32c(target, "target"), _f32c(g, "g")
+    g0 = torch.empty_like(rgb0)
+    g1 = None if rgb1 is None else torch.empty_like(rgb1)
+    gd = torch.empty(n_dp, dtype=torch.float32, device=rgb0.device) if n_dp else None
+    _lib.check(_lib.lib().ddnerf_train_loss_backward(_ptr(rgb0), _ptr(rgb1), _ptr(target), rgb0.numel(), int(n_dp), float(c0), float(c1), float(c_dp),
+                                                     _ptr(g), _ptr(g0), _ptr(g1), _ptr(gd), _stream()), "ddnerf_train_loss_backward")
+    return g0, g1, gd
+
+
 def ray_table(rays):
     """rays [n,12] -> the fused kernel's per-ray table [n,32] (fp32 words: 16 floats, then the ray's view-direction row as 32 bf16)"""
     rays = _f32c(rays, "rays")

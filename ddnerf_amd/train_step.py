@@ -8,7 +8,11 @@ import os
 import torch
 
 from . import dist as ddp
+from . import functions as F
 from . import schedules
+
+# the loss of train_model.py:156-172 as one launch + one for its gradient (ddnerf_train_loss_*); DDNERF_FUSED_LOSS=0: the torch op chain
+FUSED_LOSS = os.environ.get("DDNERF_FUSED_LOSS", "1") != "0"
 
 
 class TrainStepper:
@@ -40,14 +44,21 @@ class TrainStepper:
             for gp in o.param_groups:
                 gp["lr"] = lr
         out = model.run_iter(ray_origins, ray_directions, ray_rad, mode="train", rgb_target=target)
-        losses = [torch.nn.functional.mse_loss(out[j]["rgb"], target) for j in range(len(out))]
-        loss = cfg.train_params.loss_coeficients[0] * losses[0]                                # :159-161 (no `0 +` launch in front)
-        for j in range(1, len(out)):
-            loss = loss + cfg.train_params.loss_coeficients[j] * losses[j]
-        if self.dd:
-            dp = out[1]["dp_loss"].mean()                                                      # :163-167
-            loss = loss + cfg.train_params.dp_coeficient * dp
-            losses.append(dp)
+        lc = cfg.train_params.loss_coeficients
+        if FUSED_LOSS and len(out) == 2 and out[0]["rgb"].is_cuda:
+            # the whole of train_model.py:156-172 in one launch (and one for its gradient)
+            dp_vec = out[1]["dp_loss"] if self.dd else None
+            loss, parts = F.train_loss(out[0]["rgb"], out[1]["rgb"], target, dp_vec, lc[0], lc[1], cfg.train_params.dp_coeficient if self.dd else 0.0)
+            losses = [parts[0], parts[1]] + ([parts[2]] if self.dd else [])
+        else:
+            losses = [torch.nn.functional.mse_loss(out[j]["rgb"], target) for j in range(len(out))]
+            loss = lc[0] * losses[0]                                                               # :159-161 (no `0 +` launch in front)
+            for j in range(1, len(out)):
+                loss = loss + lc[j] * losses[j]
+            if self.dd:
+                dp = out[1]["dp_loss"].mean()                                                      # :163-167
+                loss = loss + cfg.train_params.dp_coeficient * dp
+                losses.append(dp)
         loss.backward()
         if self.buckets is not None:
             self.buckets.finish()

@@ -406,6 +406,15 @@ int ddnerf_mlp_x3_wgrad_packed_skip(const void *deltas, int drow0, const void *a
 /* fp32 [rows][ld] ([feature][sample], ld a multiple of 16) -> rows row0 .. row0 + rows - 1 of such a record. */
 int ddnerf_mlp_x3_split(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream);
 
+/* a15  the loss of one training iteration, train_model.py:156-172, as one launch (+ one for its gradient):
+ *   loss = c0 * mse(rgb0, target) + c1 * mse(rgb1, target) + c_dp * mean(dp[0..n_dp))      (rgb1 may be NULL: one level; n_dp may be 0)
+ * count = number of floats of an rgb tensor (3 n).  out [4] = {loss, mse0, mse1, mean dp}.  Backward: g [1] = the upstream gradient of
+ * the loss (NULL = 1): g_rgb0 / g_rgb1 [count], g_dp [n_dp]. */
+int ddnerf_train_loss_forward(const float *rgb0, const float *rgb1, const float *target, long count, const float *dp, int n_dp, float c0,
+                              float c1, float c_dp, float *out, ddnerf_stream_t stream);
+int ddnerf_train_loss_backward(const float *rgb0, const float *rgb1, const float *target, long count, int n_dp, float c0, float c1, float c_dp,
+                               const float *g, float *g_rgb0, float *g_rgb1, float *g_dp, ddnerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

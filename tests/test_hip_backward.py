@@ -430,3 +430,31 @@ def test_training_kernels_at_full_size(ops):
     off = (a - b).abs() > 2.0 ** -7 * a.abs() + 1e-4 * float(a.abs().max())
     assert float(off.float().mean()) <= 1e-4, float(off.float().mean())            # kink flips only (measured ~1e-5)
     assert float((a - b).norm()) <= 3e-3 * float(a.norm())
+
+
+@pytest.mark.parametrize("n,n_dp,levels", [(4096, 1, 2), (333, 3, 2), (1000, 0, 2)])
+def test_fused_training_loss_equals_the_torch_op_chain(n, n_dp, levels):
+    """ddnerf_train_loss_forward / _backward (one launch each) against train_model.py:156-172 spelled out in torch ops with autograd"""
+    from ddnerf_amd import functions as F
+
+    g = torch.Generator(device="cuda").manual_seed(n)
+    rgb0 = torch.rand(n, 3, device="cuda", generator=g, requires_grad=True)
+    rgb1 = torch.rand(n, 3, device="cuda", generator=g, requires_grad=True)
+    tgt = torch.rand(n, 3, device="cuda", generator=g)
+    dp = (torch.rand(n_dp, device="cuda", generator=g) * 3).requires_grad_() if n_dp else None
+    c0, c1, cdp = 1.0, 0.7, 0.05
+    ref = c0 * torch.nn.functional.mse_loss(rgb0, tgt) + c1 * torch.nn.functional.mse_loss(rgb1, tgt)
+    if n_dp:
+        ref = ref + cdp * dp.mean()
+    (ref * 1.5).backward()
+    want = [rgb0.grad.clone(), rgb1.grad.clone(), dp.grad.clone() if n_dp else None]
+    for t in (rgb0, rgb1, dp):
+        if t is not None:
+            t.grad = None
+    loss, parts = F.train_loss(rgb0, rgb1, tgt, dp, c0, c1, cdp)
+    (loss * 1.5).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-7 * abs(float(ref)) + 1e-9
+    assert abs(float(parts[0]) - float(torch.nn.functional.mse_loss(rgb0, tgt))) <= 2e-7 and (not n_dp or abs(float(parts[2]) - float(dp.mean())) <= 1e-6)
+    for got, w in zip((rgb0.grad, rgb1.grad, dp.grad if n_dp else None), want):
+        if w is not None:
+            assert torch.allclose(got, w, rtol=2e-6, atol=1e-12), float((got - w).abs().max())

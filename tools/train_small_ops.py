@@ -27,26 +27,55 @@ def main():
         stepper.step(ro, rd, rad, tgt)
     torch.cuda.synchronize()
     steps = 3
-    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA], with_stack=True) as prof:
+    rf = torch.profiler.record_function
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]) as prof:
         for _ in range(steps):
-            stepper.step(ro, rd, rad, tgt)
+            # TrainStepper.step, phase by phase (train_step.py)
+            with rf("PHASE forward"):
+                stepper.smooth.apply(model.cfg, stepper.iter)
+                model.train()
+                out = model.run_iter(ro, rd, rad, mode="train", rgb_target=tgt)
+            with rf("PHASE loss"):
+                losses = [torch.nn.functional.mse_loss(out[j]["rgb"], tgt) for j in range(len(out))]
+                loss = cfg.train_params.loss_coeficients[0] * losses[0]
+                for j in range(1, len(out)):
+                    loss = loss + cfg.train_params.loss_coeficients[j] * losses[j]
+                if stepper.dd:
+                    loss = loss + cfg.train_params.dp_coeficient * out[1]["dp_loss"].mean()
+            with rf("PHASE backward"):
+                loss.backward()
+            with rf("PHASE optimizer"):
+                for o in stepper.optims:
+                    o.step()
+                    o.zero_grad()
+            stepper.iter += 1
         torch.cuda.synchronize()
     groups = collections.Counter()
     times = collections.Counter()
+
+    def where(ev):
+        chain, p = [], ev.cpu_parent
+        while p is not None:
+            if p.name.startswith("PHASE ") or "evaluate_function" in p.name or p.name.endswith("Backward") or "Function" in p.name:
+                chain.append(p.name.replace("autograd::engine::evaluate_function: ", ""))
+            p = p.cpu_parent
+        return " <- ".join(chain[:2]) or "(no parent)"
+
     for ev in prof.events():
-        if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or ev.device_time_total > 20 * max(1, len(ev.kernels)):
+        if not ev.name.startswith("aten::") or not ev.kernels:
             continue
-        if not ev.kernels:
+        dt = sum(k.duration for k in ev.kernels)
+        if dt > 20 * len(ev.kernels):
             continue
-        frames = [f for f in (ev.stack or []) if "/root/repo" in f or ROOT in f or "ddnerf_amd" in f or "train_step" in f]
-        where = " <- ".join(os.path.basename(f.split(",")[0]) + ":" + f.split("(")[-1].split(")")[0] if "(" in f else f for f in frames[:2]) or "(autograd engine / no repository frame)"
-        key = (ev.name, where)
+        if any(c.kernels for c in ev.cpu_children if c.name.startswith("aten::")):
+            continue            # (count the innermost op that launched)
+        key = (ev.name, where(ev))
         groups[key] += len(ev.kernels)
-        times[key] += ev.device_time_total
-    print("%-28s %8s %10s  %s" % ("op", "launches", "us / step", "where (innermost repository frames)"))
+        times[key] += dt
+    print("%-26s %8s %10s  %s" % ("op", "launches", "us / step", "where"))
     for key, n in sorted(groups.items(), key=lambda kv: -times[kv[0]]):
-        print("%-28s %8.1f %10.1f  %s" % (key[0], n / steps, times[key] / steps, key[1]))
-    print("total: %.1f launches, %.1f us per step" % (sum(groups.values()) / steps, sum(times.values()) / steps))
+        print("%-26s %8.1f %10.1f  %s" % (key[0], n / steps, times[key] / steps, key[1]))
+    print("total: %.1f launches, %.1f us of kernel time per step (each also costs its launch gap on the step's one stream)" % (sum(groups.values()) / steps, sum(times.values()) / steps))
 
 
 if __name__ == "__main__":
