@@ -693,6 +693,46 @@ def gen_grad4096():
         del out, loss, model
 
 
+def gen_grad4096_trained():
+    """gen_grad4096 at the TRAINED state: the reference's parameter gradients of one 4096-ray training pass (perturb / noise off) with
+    the networks of its own 3000-iteration run (trained_weights_dd_blender.npz) and the procedural targets they were trained on, dp
+    term on (config value) and off -- the backward kernels on trained activations (sparse ReLU patterns, peaked weights)."""
+    n, nc, nf = 4096, 64, 128
+    w = np.load(os.path.join(HERE, "trained_weights_dd_blender.npz"))
+    for tag, dp_on in (("dp1", True), ("dp0", False)):
+        cfg = load_cfg(CFG_OF["blender"], nc, nf, "blender")
+        for mode in ("train", "validation"):
+            cfg.nerf[mode]["radiance_field_noise_std"] = 0.0
+            cfg.nerf[mode]["perturb"] = False
+        if not dp_on:
+            cfg.train_params.dp_coeficient = 0.0
+        if cfg.train_params.set_automatic_dist_reg_coeficient:
+            cfg.train_params.dist_reg_coeficient = min(max(1 / cfg.nerf.train.num_coarse, 0.01), 0.12)
+        cfg.train_params.gaussian_smooth_factor = float(w["meta"][1])       # (the smoothing schedule's value at iteration 2999)
+        model = ref_models.DDNerfModel(cfg)
+        model.coarse.load_state_dict({k[2:]: T(w[k]) for k in w.files if k.startswith("c.")})
+        model.fine.load_state_dict({k[2:]: T(w[k]) for k in w.files if k.startswith("f.")})
+        ro, rd, rad, _ = synthetic.make_rays("blender", n, seed=6)
+        tgt = synthetic.procedural_targets(ro, rd)
+        model.train()
+        out = model.run_iter(T(ro), T(rd), T(rad), mode="train", rgb_target=T(tgt))
+        mses = [torch.nn.functional.mse_loss(out[j]["rgb"], T(tgt)) for j in range(2)]
+        loss = sum(cfg.train_params.loss_coeficients[j] * mses[j] for j in range(2))
+        loss = loss + cfg.train_params.dp_coeficient * out[1]["dp_loss"].mean()
+        loss.backward()
+        rec = {"loss": loss.detach(), "mse": torch.stack([m.detach() for m in mses]), "dp_loss": out[1]["dp_loss"].detach()}
+        for pfx, net in (("c", model.coarse), ("f", model.fine)):
+            for name, p in net.named_parameters():
+                g = p.grad.reshape(-1)
+                rec["g%s_%s_sub" % (pfx, name)] = g[::61].clone()
+                rec["g%s_%s_stat" % (pfx, name)] = torch.stack([g.double().norm(), g.double().sum()])
+        print("grad4096_trained", tag, float(loss), [float(m) for m in mses], flush=True)
+        save("grad4096_trained_" + tag, meta=np.array([n, nc, nf, 1.0, 0.0, float(cfg.dataset.near), float(cfg.dataset.far),
+                                                        float(cfg.train_params.dist_reg_coeficient), float(cfg.train_params.gaussian_smooth_factor),
+                                                        int(cfg.train_params.pdf_padding), float(cfg.train_params.dp_coeficient)]), **rec)
+        del out, loss, model
+
+
 def gen_train1500():
     """1500 iterations of the reference's training loop with the schedule train_model.py hard-wires (:101-107: log-lerp 5e-4 -> 5e-6 over
     cfg.experiment.train_iters with the 2500-step x0.01 warm-up), i.e. the FIRST 1500 steps of a real run, DDNerfModel, 256 fresh rays per

@@ -63,16 +63,27 @@ def _cfg2_train_model(sharpen, dp_coef, mlp_dtype, meta):
 
 
 @pytest.mark.parametrize("mlp_dtype", ["fp32", "x3"])
-@pytest.mark.parametrize("tag", ["dp0", "dp1"])
+@pytest.mark.parametrize("tag", ["cfg2_dp0", "cfg2_dp1", "trained_dp0", "trained_dp1"])
 def test_gradients_at_4096_rays(tag, mlp_dtype):
-    """loss.backward() of the whole cfg2-size training pass vs the reference's parameter gradients (every 61st entry + norms)"""
-    g = _load("grad4096_cfg2_" + tag)
+    """loss.backward() of the whole cfg2-size training pass vs the reference's parameter gradients (every 61st entry + norms); "trained":
+    at the state the reference's own 3000-iteration run reached (make_golden.py gen_grad4096_trained), on the targets it was trained on"""
+    g = _load("grad4096_" + tag)
     n = int(g["meta"][0])
     dp_coef = float(g["meta"][10])
     model = _cfg2_train_model(float(g["meta"][3]), dp_coef, mlp_dtype, g["meta"])
+    trained = tag.startswith("trained")
+    if trained:
+        from _cases import trained_state_dicts
+
+        sd_c, sd_f = trained_state_dicts()
+        model.coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+        model.fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
     model.cfg.train_params.dp_coeficient = dp_coef
     model.train()
     ro, rd, rad, tgt = (torch.from_numpy(x).cuda() for x in synthetic.make_rays("blender", n, 6))
+    if trained:
+        o_, d_, _, _ = synthetic.make_rays("blender", n, 6)
+        tgt = torch.from_numpy(synthetic.procedural_targets(o_, d_)).cuda()
     out = model.run_iter(ro, rd, rad, mode="train", rgb_target=tgt)
     coef = model.cfg.train_params.loss_coeficients
     mses = [torch.nn.functional.mse_loss(out[j]["rgb"], tgt) for j in range(2)]
@@ -84,7 +95,9 @@ def test_gradients_at_4096_rays(tag, mlp_dtype):
     for pfx, net in (("c", model.coarse), ("f", model.fine)):
         # (the dp-loss gradient into the coarse net is ill-conditioned in the reference itself: tests/test_hip_backward.py)
         chaotic = pfx == "c" and dp_coef != 0.0
-        tol = 0.25 if chaotic else 1e-2
+        # (trained state: the MSE gradients are tiny there -- loss 6.6e-4 -- so the coarse net's gradient IS the dp term's ill-conditioned
+        # one: measured 0.43 of a parameter's norm, 0.2 - 0.3 of the whole net's; the dp0 fixture holds the same backward path to 1e-2)
+        tol = (0.7 if trained else 0.25) if chaotic else 1e-2
         mine_all, ref_all = [], []
         for pname, p in net.named_parameters():
             ref_sub = torch.from_numpy(g["g%s_%s_sub" % (pfx, pname)]).double()
@@ -92,10 +105,12 @@ def test_gradients_at_4096_rays(tag, mlp_dtype):
             mine = p.grad.reshape(-1)[::61].cpu().double()
             mine_all.append(mine)
             ref_all.append(ref_sub)
+            if chaotic and trained:
+                continue          # (per parameter the sampled entries of this gradient are noise against noise: only the whole net is held, below)
             assert float((mine - ref_sub).norm()) <= tol * float(ref_sub.norm()) + 1e-12, (pfx, pname)
             assert abs(float(p.grad.double().norm()) - ref_norm) <= tol * ref_norm + 1e-9, (pfx, pname)
         a, b = torch.cat(mine_all), torch.cat(ref_all)
-        assert float((a - b).norm()) <= (3e-2 if chaotic else 5e-3) * float(b.norm()), (pfx, float((a - b).norm() / b.norm()))
+        assert float((a - b).norm()) <= ((0.5 if trained else 3e-2) if chaotic else 5e-3) * float(b.norm()), (pfx, float((a - b).norm() / b.norm()))
 
 
 def _psnr(m):
