@@ -118,6 +118,81 @@ __device__ __forceinline__ void ddn_wave_sync() {
 
 // Same order, but the 8 vector lanes are 8 GPU lanes (lane l < 8 owns vector lane l); the final
 // lane-0..7 chain runs on lane 0 after a gather.  Used where a whole wave is available.
+// ---- the serial chains of the wave-per-ray kernels (ONE lane runs them: torch.cumprod / torch.cumsum / a j-ascending fp32 sum, step for step) ----
+// Round 5, measured (tools/comp_variants.py, the fine compositing launch: 15.8 us, of which the cumprod chain 4.6 and the rgb sum 3.6):
+// * the cumprod / cumsum chains are bound by the LATENCY of the dependent double multiply / add -- ~70 cycles a step on this part, x 128 steps --,
+//   not by the instructions around it: with the conversions moved off the chain (the whole wave converting to double in front of it and back
+//   behind it: a chain of bare v_mul_f64) the launch got SLOWER (19.2 us), and batching the loads in front of the steps changed nothing.  All 4096
+//   rays' chains already run side by side (four waves per SIMD), so one chain's latency is the floor of this phase; a lane-per-ray layout would
+//   not shorten it.  The helpers below keep the batched form (same time, one place for the arithmetic).
+// * the rgb sum was two dependent instructions a step on three lanes; the products are now formed in place by the whole wave and the chain is the
+//   add alone: 3.6 -> 2.2 us.
+// The same operations on the same values in the same order: bit-identical results.
+#define DDN_CHAIN_BATCH 16
+
+// torch.cumprod, exclusive (general_utils/nerf_helpers.py:43-64): x[j] <- fp32(prod_{i<j} x[i]), running product in double.  In place, one lane.
+__device__ __forceinline__ void ddn_chain_cumprod_exclusive(float *x, int n) {
+    double p = 1.0;
+    int j = 0;
+    for (; j + DDN_CHAIN_BATCH <= n; j += DDN_CHAIN_BATCH) {
+        float v[DDN_CHAIN_BATCH], o[DDN_CHAIN_BATCH];
+#pragma unroll
+        for (int k = 0; k < DDN_CHAIN_BATCH; ++k) v[k] = x[j + k];
+#pragma unroll
+        for (int k = 0; k < DDN_CHAIN_BATCH; ++k) {
+            o[k] = (float)p;
+            p *= (double)v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < DDN_CHAIN_BATCH; ++k) x[j + k] = o[k];
+    }
+    for (; j < n; ++j) {
+        const float v = x[j];
+        x[j] = (float)p;
+        p *= (double)v;
+    }
+}
+
+// torch.cumsum (double running sum, fp32 prefixes) clamped at 1, as the samplers and the dp loss build their cdf (models/samplers.py:88-91,
+// models/dd_utils.py:38-41): cdf[0] = 0, cdf[j + 1] = min(1, fp32(sum_{i <= j} p[i])) for j < nc - 1, cdf[nc] = 1.  p and cdf do not overlap.  One lane.
+__device__ __forceinline__ void ddn_chain_cdf(const float *__restrict__ p, float *__restrict__ cdf, int nc) {
+    double a = 0.0;
+    cdf[0] = 0.0f;
+    int j = 0;
+    for (; j + DDN_CHAIN_BATCH <= nc - 1; j += DDN_CHAIN_BATCH) {
+        float v[DDN_CHAIN_BATCH], o[DDN_CHAIN_BATCH];
+#pragma unroll
+        for (int k = 0; k < DDN_CHAIN_BATCH; ++k) v[k] = p[j + k];
+#pragma unroll
+        for (int k = 0; k < DDN_CHAIN_BATCH; ++k) {
+            a += (double)v[k];
+            o[k] = fminf(1.0f, (float)a);
+        }
+#pragma unroll
+        for (int k = 0; k < DDN_CHAIN_BATCH; ++k) cdf[j + 1 + k] = o[k];
+    }
+    for (; j < nc - 1; ++j) {
+        a += (double)p[j];
+        cdf[j + 1] = fminf(1.0f, (float)a);
+    }
+    cdf[nc] = 1.0f;
+}
+
+// sum_j c[stride * j], j ascending, fp32 (the products w_j * rgb_j of torch.sum(w[..., None] * rgb, dim = -2) were formed in place by the whole wave)
+__device__ __forceinline__ float ddn_chain_sum_strided(const float *__restrict__ c, int stride, int n) {
+    float s = 0.0f;
+    int j = 0;
+    for (; j + DDN_CHAIN_BATCH <= n; j += DDN_CHAIN_BATCH) {
+        float b[DDN_CHAIN_BATCH];
+#pragma unroll
+        for (int k = 0; k < DDN_CHAIN_BATCH; ++k) b[k] = c[stride * (j + k)];
+#pragma unroll
+        for (int k = 0; k < DDN_CHAIN_BATCH; ++k) s = s + b[k];
+    }
+    for (; j < n; ++j) s = s + c[stride * j];
+    return s;
+}
+
 __device__ inline float ddn_aten_sum_wave(const float *x, int n, int lane) {
     if (n < 8) {
         float r = 0.0f;

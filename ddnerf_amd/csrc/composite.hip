@@ -155,14 +155,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
         }
     }
     ddn_wave_sync();
-    if (live && lane == 0) {  // exclusive cumprod, double accumulator, fp32 prefixes
-        double p = 1.0;
-        for (int j = 0; j < S; ++j) {
-            float x = trans[j];
-            trans[j] = (float)p;
-            p *= (double)x;
-        }
-    }
+#ifndef COMP_EXP_NOCHAIN   // (timing-only experiment builds, tools/comp_variants.py: what does the serial chain cost?)
+    if (live && lane == 0) ddn_chain_cumprod_exclusive(trans, S);  // double accumulator, fp32 prefixes
+#endif
     ddn_wave_sync();
     if (live) {
         for (int j = lane; j < S; j += 64) {
@@ -175,9 +170,19 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     }
     ddn_wave_sync();
     float c_sum = 0.0f;
-    if (live && lane < 3) {  // rgb_map = sum_j w_j * rgb_j, j ascending (:47-48)
-        for (int j = 0; j < S; ++j) c_sum = c_sum + wpre[j] * rgbs[3 * j + lane];
-    }
+#ifndef COMP_EXP_NORGBSUM
+    // rgb_map = sum_j w_j * rgb_j, j ascending (:47-48): the products by the whole wave, in place (rgbs is not read again), the three sums by
+    // three lanes
+    if (live)
+        for (int j = lane; j < S; j += 64) {
+            const float w = wpre[j];
+            rgbs[3 * j] = w * rgbs[3 * j];
+            rgbs[3 * j + 1] = w * rgbs[3 * j + 1];
+            rgbs[3 * j + 2] = w * rgbs[3 * j + 2];
+        }
+    ddn_wave_sync();
+    if (live && lane < 3) c_sum = ddn_chain_sum_strided(rgbs + lane, 3, S);
+#endif
     float wsum = ddn_aten_sum_wave(wpost, S, lane);                     // :58 and :70 (same operand)
     if constexpr (HEAD) {  // models/models.py:292-295 (dd_records_count_kernel): bins with w / sum(w) > 0.1
         if (live) {
@@ -423,14 +428,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             trans[j] = 1.0f - a + 1e-10f;
         }
     ddn_wave_sync();
-    if (live && lane == 0) {  // same transmittance arithmetic as the forward kernel
-        double p = 1.0;
-        for (int j = 0; j < S; ++j) {
-            float x = trans[j];
-            trans[j] = (float)p;
-            p *= (double)x;
-        }
-    }
+    if (live && lane == 0) ddn_chain_cumprod_exclusive(trans, S);  // same transmittance arithmetic as the forward kernel
     ddn_wave_sync();
     if (live)
         for (int j = lane; j < S; j += 64) {

@@ -92,15 +92,7 @@ __global__ __launch_bounds__(256) void dpl_rows_kernel(
         for (int j = lane; j < nf; j += 64) p1[j] = p1[j] / s1;
     }
     ddn_wave_sync();
-    if (live && lane == 0) {  // torch.cumsum order (double running sum), clamp at 1      :38-41
-        double a = 0.0;
-        cdf[0] = 0.0f;
-        for (int j = 0; j < nc - 1; ++j) {
-            a += (double)p0[j];
-            cdf[j + 1] = fminf(1.0f, (float)a);
-        }
-        cdf[nc] = 1.0f;
-    }
+    if (live && lane == 0) ddn_chain_cdf(p0, cdf, nc);  // torch.cumsum order (double running sum), clamp at 1      :38-41
     ddn_wave_sync();
     if (live) {
         for (int m = lane; m <= nf; m += 64) {

@@ -26,15 +26,7 @@ __device__ __forceinline__ void build_cdf(const float *__restrict__ w, int nc, i
     if (live)
         for (int j = lane; j < nc; j += 64) wp[j] = wp[j] / sum;             // pdf
     ddn_wave_sync();
-    if (live && lane == 0) {  // torch.cumsum: double running sum, fp32 prefixes; clamp at 1   :88-91
-        double a = 0.0;
-        cdf[0] = 0.0f;
-        for (int j = 0; j < nc - 1; ++j) {
-            a += (double)wp[j];
-            cdf[j + 1] = fminf(1.0f, (float)a);
-        }
-        cdf[nc] = 1.0f;
-    }
+    if (live && lane == 0) ddn_chain_cdf(wp, cdf, nc);  // torch.cumsum: double running sum, fp32 prefixes; clamp at 1   :88-91
     ddn_wave_sync();
 }
 
