@@ -120,11 +120,12 @@ __device__ __forceinline__ void ddn_wave_sync() {
 // lane-0..7 chain runs on lane 0 after a gather.  Used where a whole wave is available.
 // ---- the serial chains of the wave-per-ray kernels (ONE lane runs them: torch.cumprod / torch.cumsum / a j-ascending fp32 sum, step for step) ----
 // Round 5, measured (tools/comp_variants.py, the fine compositing launch: 15.8 us, of which the cumprod chain 4.6 and the rgb sum 3.6):
-// * the cumprod / cumsum chains are bound by the LATENCY of the dependent double multiply / add -- ~70 cycles a step on this part, x 128 steps --,
-//   not by the instructions around it: with the conversions moved off the chain (the whole wave converting to double in front of it and back
-//   behind it: a chain of bare v_mul_f64) the launch got SLOWER (19.2 us), and batching the loads in front of the steps changed nothing.  All 4096
-//   rays' chains already run side by side (four waves per SIMD), so one chain's latency is the floor of this phase; a lane-per-ray layout would
-//   not shorten it.  The helpers below keep the batched form (same time, one place for the arithmetic).
+// * a cumprod step is three double-class instructions on the chain's lane (v_cvt_f64_f32 of the factor, the dependent v_mul_f64, v_cvt_f32_f64 of
+//   the prefix) at 10 - 16 cycles each (tools/calib/dp_chain.hip, profiles/r05_dp_chain_microbench.log: a dependent v_mul_f64 / v_add_f64 step costs
+//   15 cycles with one lane active, 26 with the conversion of its result): ~70 cycles a step in the kernel, x 128 steps = the 4.6 us.  Batching the
+//   loads in front of the steps changed nothing (the helpers below keep that form: one place for the arithmetic); taking the conversions OFF the
+//   chain (the whole wave converting to double in front of it and back behind it, the chain a run of bare v_mul_f64 on doubles in LDS) made the
+//   launch SLOWER (19.2 us) and was not kept.  All 4096 rays' chains already run side by side, four waves per SIMD.
 // * the rgb sum was two dependent instructions a step on three lanes; the products are now formed in place by the whole wave and the chain is the
 //   add alone: 3.6 -> 2.2 us.
 // The same operations on the same values in the same order: bit-identical results.
