@@ -19,6 +19,10 @@ _SIGS = {
     "ddnerf_encode": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp]),
     "ddnerf_encode_first_cycle": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int,
                                             C.c_int, c_fp]),
+    "ddnerf_encode_rays": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "ddnerf_encode_first_cycle_rays": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "ddnerf_mlp_x3_forward_rays": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
+    "ddnerf_mlp_f32_forward_rays": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
     "ddnerf_mlp_f32_packed_floats": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_f32_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_f32_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),

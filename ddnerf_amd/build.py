@@ -41,6 +41,8 @@ SOURCES = {
     # (no SLP vectoriser: it packs the two subtractions of the hi / lo split into v_pk_add_f32, which costs more issue time
     # beside MFMAs than two v_sub_f32)
     "mlp_x3_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+    # the x3 inference kernel with the view-direction columns from a per-ray table (ddnerf_mlp_x3_forward_rays)
+    "mlp_x3_fwd_rays.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     "mlp_x3_fwd_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     "mlp_x3_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     # the x3 training tier's strict mode (DDNERF_X3_WGRAD=exact): the round-2 kernels that record exact hi/lo words
@@ -52,7 +54,7 @@ SOURCES = {
 # kernels whose matrix instructions are inline asm: the compiler's assembly is scanned for dependent pairs that sit closer
 # than the wait states nobody pads (csrc/check_asm_hazards.py); a violation fails the build
 CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_bf16_g2.hip": "mlp_bf16g2_fwd_kernel", "mlp_bf16_g2e.hip": "mlp_bf16g2e_fwd_kernel", "mlp_f16.hip": "mlp_f16_fwd_kernel",
-           "mlp_f16_g2.hip": "mlp_f16g2_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel",
+           "mlp_f16_g2.hip": "mlp_f16g2_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel", "mlp_x3_fwd_rays.hip": "mlp_x3_fwd16_rays_kernel",
            "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel", "mlp_x3_bwd.hip": "mlp_x3_bwd16_kernel",
            "mlp_x3e_fwd_train.hip": "mlp_x3e_fwd16_train_kernel", "mlp_x3e_bwd.hip": "mlp_x3e_bwd16_kernel"}
 

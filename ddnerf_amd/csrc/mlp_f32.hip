@@ -131,6 +131,13 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_fwd_kernel(const float *__rest
     __shared__ __attribute__((aligned(16))) float lds[F32_FWD_LDS_FLOATS];
     mlp_f32_forward_tiles<DEPTH>(lds, feat, packed, 4u * (unsigned)pl.bias_off[0], raw, M, NoRecord{});
 }
+// the same with the view-direction columns from a per-ray table (ddnerf_mlp_f32_forward_rays)
+template <bool DEPTH>
+__global__ __launch_bounds__(256, 1) void mlp_f32_fwd_rays_kernel(const float *__restrict__ feat, const float *__restrict__ dirs, unsigned magic,
+                                                                  const float *__restrict__ packed, PackPlan pl, float *__restrict__ raw, long M) {
+    __shared__ __attribute__((aligned(16))) float lds[F32_FWD_LDS_FLOATS];
+    mlp_f32_forward_tiles<DEPTH>(lds, feat, packed, 4u * (unsigned)pl.bias_off[0], raw, M, NoRecord{}, F32Dirs{dirs, magic});
+}
 
 #ifdef F32_STAMP_TILE
 DDN_EXPORT int ddnerf_debug_f32_tile_stamps(unsigned long long *host_out) {
@@ -155,5 +162,25 @@ DDN_EXPORT int ddnerf_mlp_f32_forward(const float *feat, const float *packed, in
         hipLaunchKernelGGL(mlp_f32_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, pl, raw, M);
     else
         hipLaunchKernelGGL(mlp_f32_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, pl, raw, M);
+    return ddn_launch_status();
+}
+
+// feat [n*S,128] with columns 96..127 NOT read; dirs [n,32]: the rays' view-direction columns (ddnerf_encode_rays).  Same outputs as
+// ddnerf_mlp_f32_forward on rows that carry the columns.  n * S^2 < 2^32 (the ray of a sample comes from a 32-bit multiply-high).
+DDN_EXPORT int ddnerf_mlp_f32_forward_rays(const float *feat, const float *dirs, int S, const float *packed, int depth_head, float *raw, long M,
+                                           ddnerf_stream_t stream) {
+    DDN_REQUIRE(feat && dirs && packed && raw, DDNERF_E_ARG);
+    DDN_REQUIRE(M > 0 && S > 0 && M % S == 0, DDNERF_E_ARG);
+    DDN_REQUIRE((unsigned long long)M * (unsigned long long)S < (1ull << 32), DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(dirs, 16) && ddn_aligned(packed, 16) && ddn_aligned(raw, 16), DDNERF_E_ALIGN);
+    PackPlan pl = make_plan(depth_head);
+    const long ntiles = (M + 127) / 128, cus = ddn_cu_count();
+    dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));
+    const unsigned magic = (unsigned)(((1ull << 32) + (unsigned)S - 1) / (unsigned)S);   // (S = 1: 2^32 does not fit -- the rows ARE the rays then)
+    DDN_REQUIRE(S > 1, DDNERF_E_RANGE);
+    if (depth_head)
+        hipLaunchKernelGGL(mlp_f32_fwd_rays_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, dirs, magic, packed, pl, raw, M);
+    else
+        hipLaunchKernelGGL(mlp_f32_fwd_rays_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, dirs, magic, packed, pl, raw, M);
     return ddn_launch_status();
 }

@@ -340,7 +340,9 @@ struct FirstCycle {
 template <int KIND, bool FIRST>   // feature rows: 0 fp32 (natural column order), 1 bf16, 2 fp16 (both in MFMA k-order)
 __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ rays_in, const float *__restrict__ t_vals_in,
                                                      void *__restrict__ feat_, int n, int S, int cylinder, FirstCycle fc,
-                                                     float *__restrict__ rays_out, float *__restrict__ t_out) {
+                                                     float *__restrict__ rays_out, float *__restrict__ t_out, float *__restrict__ dirs_out) {
+    // dirs_out != NULL (fp32 rows only; ddnerf_encode_rays): the 32 view-direction columns are written ONCE PER RAY into dirs_out [n,32] -- the
+    // reference computes them per ray and broadcasts (models/models.py:128-133) -- and columns 96..127 of the feature rows are left untouched
     const float *__restrict__ rays = FIRST ? rays_out : rays_in;       // (FIRST: only this block's own writes are read back, see phase 1)
     const float *__restrict__ t_vals = FIRST ? t_out : t_vals_in;
     __shared__ float g_mean[ENC_SPB][4];
@@ -406,9 +408,8 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
     // touches one ray when S is a multiple of 16, at most 16); walked from the far end of the block so that it lands on other waves
     // than phase 1
     const int ray0 = (int)(m0 / S);
+    const int nrays = (int)(((m0 + ENC_SPB < M ? m0 + ENC_SPB : M) - 1) / S) - ray0 + 1;
     {
-        const size_t mlast = (m0 + ENC_SPB < M ? m0 + ENC_SPB : M) - 1;
-        const int nrays = (int)(mlast / S) - ray0 + 1;
         for (int t2 = 255 - tid; t2 < nrays * 12; t2 += 256) {
             int lr = t2 / 12, k = t2 % 12;  // k: 0..11 -> (freq f = k/3, axis a = k%3), emits sin and cos
             int f = k / 3, a = k % 3;
@@ -505,8 +506,15 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
         }
     } else {
         float *feat = (float *)feat_;
+        if (dirs_out) {   // the rays that START in this block (their sample 0 is one of its samples): their row of the per-ray table
+            for (int e = tid; e < nrays * 8; e += 256) {
+                const int lr = e >> 3, q = e & 7;
+                if ((size_t)(ray0 + lr) * S >= m0) *(float4 *)(dirs_out + (size_t)(ray0 + lr) * 32 + 4 * q) = *(const float4 *)&dirv[lr][4 * q];
+            }
+        }
         for (int e = tid; e < ENC_SPB * DDNERF_FEAT_LD / 4; e += 256) {
             int ls = e / (DDNERF_FEAT_LD / 4), c = (e % (DDNERF_FEAT_LD / 4)) * 4;
+            if (c >= 96 && dirs_out) continue;
             if (m0 + ls < M) {
                 const float *src = c < 96 ? &row[ls][c] : &dirv[ray_of[ls]][c - 96];
                 float4 v = *(const float4 *)src;
@@ -528,13 +536,13 @@ DDN_EXPORT int ddnerf_encode(const float *rays, const float *t_vals, void *feat,
     const FirstCycle none{};
     if (feat_dtype == 0)
         hipLaunchKernelGGL((encode_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape, none,
-                           (float *)nullptr, (float *)nullptr);
+                           (float *)nullptr, (float *)nullptr, (float *)nullptr);
     else if (feat_dtype == 1)
         hipLaunchKernelGGL((encode_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape, none,
-                           (float *)nullptr, (float *)nullptr);
+                           (float *)nullptr, (float *)nullptr, (float *)nullptr);
     else
         hipLaunchKernelGGL((encode_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, rays, t_vals, feat, n, S, ray_shape, none,
-                           (float *)nullptr, (float *)nullptr);
+                           (float *)nullptr, (float *)nullptr, (float *)nullptr);
     return ddn_launch_status();
 }
 
@@ -555,12 +563,44 @@ DDN_EXPORT int ddnerf_encode_first_cycle(const float *origins, const float *dire
     const FirstCycle fc{origins, directions, radii, t_lin, near_, far_, lindisp};
     if (feat_dtype == 0)
         hipLaunchKernelGGL((encode_kernel<0, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, (const float *)nullptr, feat,
-                           n, nc, ray_shape, fc, rays, t_vals);
+                           n, nc, ray_shape, fc, rays, t_vals, (float *)nullptr);
     else if (feat_dtype == 1)
         hipLaunchKernelGGL((encode_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, (const float *)nullptr, feat,
-                           n, nc, ray_shape, fc, rays, t_vals);
+                           n, nc, ray_shape, fc, rays, t_vals, (float *)nullptr);
     else
         hipLaunchKernelGGL((encode_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, (const float *)nullptr, feat,
-                           n, nc, ray_shape, fc, rays, t_vals);
+                           n, nc, ray_shape, fc, rays, t_vals, (float *)nullptr);
+    return ddn_launch_status();
+}
+
+// a3 + a4 + a5 with the view-direction columns ONCE PER RAY (fp32 rows): feat [n*S,128] gets its columns 0..95 (96..127 are left untouched),
+// dirs [n,32] one row per ray = what columns 96..127 of every row of that ray would hold (models/models.py:128-133: the reference encodes the
+// ray's direction once and broadcasts it over the samples).  For ddnerf_mlp_f32_forward_rays / ddnerf_mlp_x3_forward_rays.
+DDN_EXPORT int ddnerf_encode_rays(const float *rays, const float *t_vals, float *feat, float *dirs, int n, int S, int ray_shape,
+                                  ddnerf_stream_t stream) {
+    DDN_REQUIRE(rays && t_vals && feat && dirs, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ray_shape == 0 || ray_shape == 1, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(dirs, 16), DDNERF_E_ALIGN);
+    size_t M = (size_t)n * S;
+    const FirstCycle none{};
+    hipLaunchKernelGGL((encode_kernel<0, false>), dim3((unsigned)((M + ENC_SPB - 1) / ENC_SPB)), dim3(256), 0, (hipStream_t)stream, rays, t_vals,
+                       (void *)feat, n, S, ray_shape, none, (float *)nullptr, (float *)nullptr, dirs);
+    return ddn_launch_status();
+}
+
+// ... and with the rays packed and the first cycle sampled in the same launch (ddnerf_encode_first_cycle, fp32 rows)
+DDN_EXPORT int ddnerf_encode_first_cycle_rays(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                                              const float *t_lin, int lindisp, float *rays, float *t_vals, float *feat, float *dirs, int n, int nc,
+                                              int ray_shape, ddnerf_stream_t stream) {
+    DDN_REQUIRE(origins && directions && radii && t_lin && rays && t_vals && feat && dirs, DDNERF_E_ARG);
+    DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(ray_shape == 0 || ray_shape == 1, DDNERF_E_RANGE);
+    DDN_REQUIRE(lindisp >= 0 && lindisp <= 2, DDNERF_E_RANGE);
+    DDN_REQUIRE(ddn_aligned(feat, 16) && ddn_aligned(dirs, 16), DDNERF_E_ALIGN);
+    size_t M = (size_t)n * nc;
+    const FirstCycle fc{origins, directions, radii, t_lin, near_, far_, lindisp};
+    hipLaunchKernelGGL((encode_kernel<0, true>), dim3((unsigned)((M + ENC_SPB - 1) / ENC_SPB)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)nullptr, (const float *)nullptr, (void *)feat, n, nc, ray_shape, fc, rays, t_vals, dirs);
     return ddn_launch_status();
 }

@@ -134,6 +134,12 @@ def encode_mlp_bf16(table, t_vals, net):
     return ops.encode_mlp_bf16_forward(table, t_vals, _packed_weights(net), net.depth_head)
 
 
+def mlp_rays(feat, dirs, S, net):
+    """inference on the fp32 / x3 kernels with the view-direction columns from the per-ray table `dirs` [n,32] (ops.encode_rays)"""
+    fwd = {"fp32": ops.mlp_f32_forward_rays, "x3": ops.mlp_x3_forward_rays}[net.mlp_dtype]
+    return fwd(feat, dirs, S, _packed_weights(net), net.depth_head)
+
+
 def mlp(feat, net):
     """feat [M,128] (fp32, or k-ordered bf16 / fp16 for the bf16 / fp16 kernels) -> raw [M,4|6]"""
     if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):

@@ -56,6 +56,9 @@ FUSE_RENDER = _os.environ.get("DDNERF_FUSE_RENDER", "1") != "0"
 # bf16 tier: run_network (models/models.py:117-142) as ONE launch, the encoder inside the MLP kernel (ops.encode_mlp_bf16_forward;
 # bit-identical to encode + MLP).  "all" both passes, "fine" the fine pass only, "0" never.
 FUSE_ENCODER = _os.environ.get("DDNERF_FUSE_ENCODER", "all")
+# fp32 / x3 tiers, inference: the view-direction columns once per RAY (ops.encode_rays + mlp_*_forward_rays), as the reference computes them
+# (models/models.py:128-133), instead of once per sample in the feature rows; same outputs.  DDNERF_RAY_DIRS=0: per-sample columns.
+RAY_DIRS = _os.environ.get("DDNERF_RAY_DIRS", "1") != "0"
 KERNEL_NOISE = _os.environ.get("DDNERF_KERNEL_NOISE", "1") != "0"   # (0: the compositing noise comes from a torch generator launch again)
 
 _const_cache = {}
@@ -279,17 +282,26 @@ class GeneralMipNerfModel(torch.nn.Module):
             self._ray_table = (ray_batch, table)
             raw = F.encode_mlp_bf16(table, t_vals, network)
             return raw.reshape(n, S, raw.shape[-1])
+        ray_dirs = RAY_DIRS and kind == "fp32" and network.mlp_dtype in ("fp32", "x3") and ops.mlp_rays_supported(S, n * S) and not F.needs_grad(network)
+        dirs = None
         if first:
             # the coarse pass of a one-chunk batch: this launch also fills ray_batch and t_vals (get_rays_batches handed them out empty)
             self._first_pending = None
             rays, t0, ro, rd, rad, t_lin, lindisp = pend
-            feat = ops.encode_first_cycle(ro, rd, rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin, lindisp,
-                                          cylinder=(shape == "cylinder"), kind=kind, out=(rays, t0))[2]
+            if ray_dirs:
+                feat, dirs = ops.encode_first_cycle_rays(ro, rd, rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin, lindisp,
+                                                         cylinder=(shape == "cylinder"), out=(rays, t0))[2:]
+            else:
+                feat = ops.encode_first_cycle(ro, rd, rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin, lindisp,
+                                              cylinder=(shape == "cylinder"), kind=kind, out=(rays, t0))[2]
         else:
             if pend is not None:     # (something else is encoded first: fill the pending tensors the plain way)
                 self._flush_first_pending()
-            feat = ops.encode(ray_batch, t_vals, cylinder=(shape == "cylinder"), kind=kind)
-        raw = F.mlp(feat, network)
+            if ray_dirs:
+                feat, dirs = ops.encode_rays(ray_batch, t_vals, cylinder=(shape == "cylinder"))
+            else:
+                feat = ops.encode(ray_batch, t_vals, cylinder=(shape == "cylinder"), kind=kind)
+        raw = F.mlp_rays(feat, dirs, S, network) if ray_dirs else F.mlp(feat, network)
         return raw.reshape(t_vals.shape[0], t_vals.shape[1] - 1, raw.shape[-1])
 
     def predict(self, ray_batch, mode, depth_analysis_validation, rgb_target=None):

@@ -70,6 +70,72 @@ def encode(rays, t_vals, cylinder=False, bf16=False, kind=None):
     return feat
 
 
+def encode_rays(rays, t_vals, cylinder=False):
+    """encode with the view-direction columns once per RAY (fp32 rows) -> (feat [n*S,128], columns 96..127 NOT written; dirs [n,32])"""
+    rays, t_vals = _f32c(rays, "rays"), _f32c(t_vals, "t_vals")
+    n, S = t_vals.shape[0], t_vals.shape[1] - 1
+    feat = torch.empty((n * S, FEAT_LD), dtype=torch.float32, device=rays.device)
+    dirs = torch.empty((n, 32), dtype=torch.float32, device=rays.device)
+    _lib.check(_lib.lib().ddnerf_encode_rays(_ptr(rays), _ptr(t_vals), _ptr(feat), _ptr(dirs), n, S, int(cylinder), _stream()), "ddnerf_encode_rays")
+    return feat, dirs
+
+
+def encode_first_cycle_rays(ray_origins, ray_directions, ray_rad, near, far, t_lin, lindisp=False, cylinder=False, out=None):
+    """encode_first_cycle (fp32 rows) with the view-direction columns once per ray -> (rays, t_vals, feat, dirs)"""
+    o = _f32c(ray_origins.reshape(-1, 3), "origins")
+    d = _f32c(ray_directions.reshape(-1, 3), "directions")
+    r = _f32c(ray_rad.reshape(-1), "radii")
+    t_lin = _f32c(t_lin, "t_lin")
+    n, nc = o.shape[0], t_lin.shape[0] - 1
+    if out is None:
+        out = (torch.empty((n, 12), dtype=torch.float32, device=o.device), torch.empty((n, nc + 1), dtype=torch.float32, device=o.device))
+    rays, t_vals = out
+    feat = torch.empty((n * nc, FEAT_LD), dtype=torch.float32, device=o.device)
+    dirs = torch.empty((n, 32), dtype=torch.float32, device=o.device)
+    _lib.check(_lib.lib().ddnerf_encode_first_cycle_rays(_ptr(o), _ptr(d), _ptr(r), float(near), float(far), _ptr(t_lin), int(lindisp), _ptr(rays),
+                                                         _ptr(t_vals), _ptr(feat), _ptr(dirs), n, nc, int(cylinder), _stream()),
+               "ddnerf_encode_first_cycle_rays")
+    return rays, t_vals, feat, dirs
+
+
+def mlp_rays_supported(S, M):
+    return S > 1 and M % S == 0 and M * S < (1 << 32)
+
+
+def mlp_f32_forward_rays(feat, dirs, S, packed, depth_head):
+    """mlp_f32_forward with the view-direction columns from the per-ray table of encode_rays"""
+    feat, dirs = _f32c(feat, "feat"), _f32c(dirs, "dirs")
+    M = feat.shape[0]
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_mlp_f32_forward_rays(_ptr(feat), _ptr(dirs), int(S), _ptr(packed), int(depth_head), _ptr(raw), M, _stream()),
+                   "ddnerf_mlp_f32_forward_rays")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw
+
+
+def mlp_x3_forward_rays(feat, dirs, S, packed, depth_head):
+    """mlp_x3_forward with the view-direction columns from the per-ray table of encode_rays"""
+    feat, dirs = _f32c(feat, "feat"), _f32c(dirs, "dirs")
+    M = feat.shape[0]
+    raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
+
+    def launch():
+        _lib.check(_lib.lib().ddnerf_mlp_x3_forward_rays(_ptr(feat), _ptr(dirs), int(S), _ptr(packed), int(depth_head), _ptr(raw), M, _stream()),
+                   "ddnerf_mlp_x3_forward_rays")
+
+    if MLP_LAUNCH_HOOK is not None:
+        MLP_LAUNCH_HOOK(M, launch)
+    else:
+        launch()
+    return raw
+
+
 def mlp_f32_pack(params_flat, depth_head):
     params_flat = _f32c(params_flat, "params")
     nfl = _lib.lib().ddnerf_mlp_f32_packed_floats(int(depth_head))

@@ -89,6 +89,15 @@ int ddnerf_encode_first_cycle(const float *origins, const float *directions, con
                               const float *t_lin, int lindisp, float *rays, float *t_vals, void *feat, int n, int nc, int ray_shape,
                               int feat_dtype, ddnerf_stream_t stream);
 
+/* a3 + a4 + a5 with the view-direction columns ONCE PER RAY, as the reference computes them (models/models.py:128-133: the ray's direction is
+ * encoded once and broadcast over its samples): fp32 rows; feat [n*S,128] gets columns 0..95 (96..127 are left untouched), dirs [n,32] one row
+ * per ray = what columns 96..127 of every row of that ray hold when ddnerf_encode writes them.  Read by ddnerf_mlp_f32_forward_rays /
+ * ddnerf_mlp_x3_forward_rays (same outputs as the plain forwards on full rows; a quarter of the row bytes less, written and read). */
+int ddnerf_encode_rays(const float *rays, const float *t_vals, float *feat, float *dirs, int n, int S, int ray_shape, ddnerf_stream_t stream);
+int ddnerf_encode_first_cycle_rays(const float *origins, const float *directions, const float *radii, float near_, float far_,
+                                   const float *t_lin, int lindisp, float *rays, float *t_vals, float *feat, float *dirs, int n, int nc,
+                                   int ray_shape, ddnerf_stream_t stream);
+
 /* a7  MipNeRFModel.forward / DepthMipNeRFModel.forward  models/base_architectures.py:40-61, 103-126
  * as ONE fused kernel (all 12/13 Linear layers, activations never leave the register file).
  *   step 1: repack the flat fp32 parameters into the kernel's LDS-image layout (once per weight update)
@@ -97,6 +106,9 @@ size_t ddnerf_mlp_f32_packed_floats(int depth_head);
 int ddnerf_mlp_f32_pack(const float *params, int depth_head, float *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_f32_forward(const float *feat, const float *packed, int depth_head, float *raw, long M,
                            ddnerf_stream_t stream);
+/* ... with the view-direction columns from the per-ray table of ddnerf_encode_rays (S = samples per ray, M = n * S, M * S < 2^32, S > 1) */
+int ddnerf_mlp_f32_forward_rays(const float *feat, const float *dirs, int S, const float *packed, int depth_head, float *raw, long M,
+                                ddnerf_stream_t stream);
 
 /* bf16-MFMA variant of the same network (bf16 operands, fp32 accumulation, fp32 biases and outputs).
  * feat: bf16 [M,128] as written by ddnerf_encode(feat_dtype=1), i.e. in MFMA "k-order": inside every 32
@@ -165,6 +177,9 @@ size_t ddnerf_mlp_x3_packed_bytes(int depth_head);
 int ddnerf_mlp_x3_pack(const float *params, int depth_head, void *packed, ddnerf_stream_t stream);
 int ddnerf_mlp_x3_forward(const float *feat, const void *packed, int depth_head, float *raw, long M,
                           ddnerf_stream_t stream);
+/* ... with the view-direction columns from the per-ray table of ddnerf_encode_rays (as ddnerf_mlp_f32_forward_rays; one launch: M < 2^23) */
+int ddnerf_mlp_x3_forward_rays(const float *feat, const float *dirs, int S, const void *packed, int depth_head, float *raw, long M,
+                               ddnerf_stream_t stream);
 
 /* x3 training kernels (same network; forward and backward-data chains in the same accuracy class): the forward that records what
  * the backward needs, the W^T images, and the fused backward-data pass -- drop-ins for ddnerf_mlp_f32_forward_train / _pack_t /

@@ -1,0 +1,91 @@
+"""The view-direction columns once per RAY (round-4 review, item 3; the reference encodes a ray's direction once and broadcasts it over the
+samples, models/models.py:128-133): ddnerf_encode_rays + ddnerf_mlp_f32_forward_rays / ddnerf_mlp_x3_forward_rays against ddnerf_encode +
+the plain forwards on rows that carry the columns -- BIT FOR BIT --, and the whole render pass with and without them."""
+import numpy as np
+import pytest
+import torch
+
+from ddnerf_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from ddnerf_amd import ops as _ops
+    return _ops
+
+
+def _flat(depth, seed, sharpen):
+    sd = synthetic.make_state_dict(depth, seed, sharpen)
+    names = [n for n, _, _ in synthetic.layer_table(depth)]
+    return torch.from_numpy(np.concatenate([np.concatenate([sd[k + ".weight"].ravel(), sd[k + ".bias"].ravel()]) for k in names])).cuda()
+
+
+def _inputs(ops, kind, n, S, seed):
+    o, d, rad, _ = synthetic.make_rays(kind, n, seed)
+    near, far = synthetic.NEAR_FAR[kind]
+    rays = ops.pack_rays(*(torch.from_numpy(x).cuda() for x in (o, d, rad)), near, far)
+    g = torch.Generator(device="cuda").manual_seed(seed + 1)
+    t = near + (far - near) * torch.sort(torch.rand(n, S + 1, device="cuda", generator=g), dim=1).values
+    return (o, d, rad), rays, t.float().contiguous()
+
+
+@pytest.mark.parametrize("kind,n,S,cyl", [("blender", 4096, 128, False), ("blender", 300, 64, False), ("llff", 41, 33, False), ("real360", 7, 5, True),
+                                          ("blender", 1000, 2, False)])
+def test_encode_rays_is_encode_without_the_view_direction_columns(ops, kind, n, S, cyl):
+    _, rays, t = _inputs(ops, kind, n, S, n + S)
+    full = ops.encode(rays, t, cylinder=cyl, kind="fp32").view(n, S, 128)
+    feat, dirs = ops.encode_rays(rays, t, cylinder=cyl)
+    torch.cuda.synchronize()
+    assert torch.equal(feat.view(n, S, 128)[..., :96], full[..., :96])
+    for j in (0, S - 1):                                   # the table row of a ray IS columns 96..127 of each of its rows
+        assert torch.equal(dirs, full[:, j, 96:])
+
+
+@pytest.mark.parametrize("mlp", ["fp32", "x3"])
+@pytest.mark.parametrize("depth", [False, True])
+def test_forward_rays_bit_identical_to_the_forward_on_full_rows(ops, mlp, depth):
+    flat = _flat(depth, 12, 20.0)
+    packed = {"fp32": ops.mlp_f32_pack, "x3": ops.mlp_x3_pack}[mlp](flat, depth)
+    plain = {"fp32": ops.mlp_f32_forward, "x3": ops.mlp_x3_forward}[mlp]
+    by_ray = {"fp32": ops.mlp_f32_forward_rays, "x3": ops.mlp_x3_forward_rays}[mlp]
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    for kind, n, S in (("blender", 4096, 128), ("blender", 4096, 64), ("llff", 41, 33), ("blender", 3, 7), ("real360", 2 * n_cu + 3, 128)):
+        _, rays, t = _inputs(ops, kind, n, S, n + 3 * S)
+        want = plain(ops.encode(rays, t, kind="fp32"), packed, depth)
+        feat, dirs = ops.encode_rays(rays, t)
+        feat.view(n, S, 128)[..., 96:] = float("nan")       # (the forward must not read them)
+        got = by_ray(feat, dirs, S, packed, depth)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (mlp, kind, n, S, int((got != want).any(dim=1).sum()))
+
+
+@pytest.mark.parametrize("mlp", ["fp32", "x3"])
+@pytest.mark.parametrize("name", ["fullsize_cfg2_dd_blender_4096_64x128", "fullsize_cfg5_mip_blender_4096_64x128", "fullsize_trained_dd_llff_4096_64x128"])
+def test_run_iter_is_the_same_with_per_ray_and_per_sample_view_directions(name, mlp, monkeypatch):
+    from _cases import load_fullsize
+    from ddnerf_amd import models as M
+    from test_hip_run_iter import build_model
+
+    c = load_fullsize(name)
+    ro, rd, rad, tgt = (torch.from_numpy(x).cuda() for x in synthetic.make_rays(c["kind"], c["n"], 1))
+
+    def run(on, chunk=None):
+        monkeypatch.setattr(M, "RAY_DIRS", on)
+        model = build_model(c)
+        model.cfg.nerf["mlp_dtype"] = mlp
+        model._set_mlp_dtype()
+        model.eval()
+        if chunk:
+            model.cfg.nerf.validation["chunksize"] = chunk
+        with torch.no_grad():
+            return model.run_iter(ro, rd, rad, mode="validation", rgb_target=tgt)
+
+    ref = run(False)
+    for chunk in (None, 1500):
+        out = run(True, chunk)
+        for lvl in ref:
+            for k in ("rgb", "depth", "acc", "disp", "weights"):
+                assert torch.equal(torch.nan_to_num(out[lvl][k]), torch.nan_to_num(ref[lvl][k])), (chunk, lvl, k)
