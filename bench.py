@@ -49,7 +49,7 @@ CONFIGS = {
     "config_360_mipnerf.yml": ("real360", "fp32", 8192),
 }
 KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2e_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"],
-                  "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+                  "x3": ["mlp_x3_fwd.hip", "mlp_x3_fwd_rays.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
                   "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
 
 
@@ -764,6 +764,13 @@ def main(argv=None):
                 roof["issued_tflops"] = round(3 * ach, 2)
                 roof["frac_issued"] = round(3 * ach / PEAK["x3"], 4)
             fused = False
+            if args.mlp in ("fp32", "x3"):
+                from ddnerf_amd import models as _m
+                from ddnerf_amd import ops as _o
+
+                roof["view_dirs_per_ray"] = bool(_m.RAY_DIRS and _o.mlp_rays_supported(args.fine, M_fine))
+                if roof["view_dirs_per_ray"]:
+                    roof["kernel"] = "mlp_%s_fwd_rays_kernel<fine> (view-direction columns from a per-ray table; %d samples/launch)" % (args.mlp, M_fine)
             if args.mlp == "bf16":
                 from ddnerf_amd import models as _m
                 from ddnerf_amd import ops as _o

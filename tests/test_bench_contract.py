@@ -32,7 +32,7 @@ def test_render_line_has_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0 and r["launches_timed"] == 3
-    assert r["traffic"] is None or r["traffic"] > 2.7e8        # at least the algorithmic bytes
+    assert r["traffic"] is None or r["traffic"] > 2.1e8        # at least the algorithmic bytes (384-byte rows + the per-ray table + outputs)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     for tier, lo in (("x3_tier", 0.1), ("bf16_tier", 0.2)):   # `frac` counts algorithmic FLOP: the x3 kernel issues 3x that

@@ -19,10 +19,12 @@ mfma = {}
 # bf16: the render step runs the FUSED kernel (mlp_bf16_g2e.hip: the encoder inside; it reads fenceposts and a per-ray table, the encoded rows
 # never exist): algorithmic bytes = 4096 x 129 fenceposts + 4096 table rows of 128 B + the outputs.  bf16u: the same step with DDNERF_FUSE_ENCODER=0
 # (encode launch + mlp_bf16g2_fwd_kernel reading 256-byte rows), for the fused-vs-unfused comparison.
-for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512 + 16)), ("bf16", "void mlp_bf16g2e_fwd_kernel<false>", 4096 * 129 * 4 + 4096 * 128 + 524288 * 16),
+# fp32 / x3 (round 5): the render path reads the view-direction columns once per RAY (ddnerf_encode_rays + *_forward_rays): 384 of a row's 512 bytes
+# + the [4096,32] fp32 table + the outputs.
+for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_rays_kernel<false>", 524288 * (384 + 16) + 4096 * 128), ("bf16", "void mlp_bf16g2e_fwd_kernel<false>", 4096 * 129 * 4 + 4096 * 128 + 524288 * 16),
                         ("bf16u", "void mlp_bf16g2_fwd_kernel<false>", 524288 * (256 + 16)),
                         ("fp16", "void mlp_f16g2_fwd_kernel<false>", 524288 * (256 + 16)),
-                        ("x3", "void mlp_x3_fwd16_kernel<false>", 524288 * (512 + 16))):
+                        ("x3", "void mlp_x3_fwd16_rays_kernel<false>", 524288 * (384 + 16) + 4096 * 128)):
     f = agg(os.path.join(P, "fetch_" + mlp, "c_counter_collection.csv"))
     w = agg(os.path.join(P, "write_" + mlp, "c_counter_collection.csv"))
     table = {}
@@ -38,7 +40,7 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_kernel<false>", 524288 * (512
     fetch_true_kb = fk["FETCH_SIZE_raw_KB"] / BF16_FACTOR if mlp in ("bf16u", "fp16") else 2 * fk["FETCH_SIZE_raw_KB"]
     traffic = (fetch_true_kb + fk["WRITE_SIZE_KB"]) * 1024
     BF = ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2e_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]
-    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": BF, "bf16u": BF, "x3": ["mlp_x3_fwd.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
+    srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": BF, "bf16u": BF, "x3": ["mlp_x3_fwd.hip", "mlp_x3_fwd_rays.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
             "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}[mlp]
     digest = hashlib.md5()
     for f_ in srcs:
