@@ -38,10 +38,12 @@ _SIGS = {
     "ddnerf_train_loss_forward": (C.c_int, [c_fp, c_fp, c_fp, C.c_long, c_fp, C.c_int, C.c_float, C.c_float, C.c_float, c_fp, c_fp]),
     "ddnerf_train_loss_backward": (C.c_int, [c_fp, c_fp, c_fp, C.c_long, C.c_int, C.c_float, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_ray_table_bytes": (C.c_size_t, [C.c_int]),
-    "ddnerf_ray_table": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
-    "ddnerf_pack_rays_first_cycle_table": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "ddnerf_ray_table": (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, c_fp]),
+    "ddnerf_pack_rays_first_cycle_table": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
     "ddnerf_encode_mlp_bf16_scratch_bytes": (C.c_size_t, []),
     "ddnerf_encode_mlp_bf16_forward": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
+    "ddnerf_encode_mlp_f16_scratch_bytes": (C.c_size_t, []),
+    "ddnerf_encode_mlp_f16_forward": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_f16_packed_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_f16_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_f16_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),

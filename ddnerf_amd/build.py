@@ -35,6 +35,7 @@ SOURCES = {
     # the same body with the encoder inside (Gen(fused=True)): cast_rays + IPE + MLP in one kernel; its per-ray table repeats
     # rays_encode.hip's arithmetic
     "mlp_bf16_g2e.hip": EXACT,
+    "mlp_f16_g2e.hip": EXACT,
     # the fp16 tier: the same two kernels on the f16 forms of the MFMA and of the re-pack conversion
     "mlp_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_DISPATCH"],
     "mlp_f16_g2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DBF16_DISPATCH"],
@@ -53,7 +54,7 @@ SOURCES = {
 
 # kernels whose matrix instructions are inline asm: the compiler's assembly is scanned for dependent pairs that sit closer
 # than the wait states nobody pads (csrc/check_asm_hazards.py); a violation fails the build
-CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_bf16_g2.hip": "mlp_bf16g2_fwd_kernel", "mlp_bf16_g2e.hip": "mlp_bf16g2e_fwd_kernel", "mlp_f16.hip": "mlp_f16_fwd_kernel",
+CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_bf16_g2.hip": "mlp_bf16g2_fwd_kernel", "mlp_bf16_g2e.hip": "mlp_bf16g2e_fwd_kernel", "mlp_f16_g2e.hip": "mlp_f16g2e_fwd_kernel", "mlp_f16.hip": "mlp_f16_fwd_kernel",
            "mlp_f16_g2.hip": "mlp_f16g2_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel", "mlp_x3_fwd_rays.hip": "mlp_x3_fwd16_rays_kernel",
            "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel", "mlp_x3_bwd.hip": "mlp_x3_bwd16_kernel",
            "mlp_x3e_fwd_train.hip": "mlp_x3e_fwd16_train_kernel", "mlp_x3e_bwd.hip": "mlp_x3e_bwd16_kernel"}
@@ -61,7 +62,7 @@ CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_bf16_g2.hip": "mlp_bf16g2
 
 # kernels whose tile body is one block of assembly that owns the whole vector register file from its first iteration on: the loop
 # that the compiler wraps around it must be scalar code only
-ASM_BODY = {"mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_f16_g2.hip"}
+ASM_BODY = {"mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_f16_g2.hip", "mlp_f16_g2e.hip"}
 
 
 def _compile_checked(cmd, src, obj, kernel, verbose):
@@ -139,7 +140,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     # (sources include sources -- mlp_f32_train_rec.hip is mlp_f32_train.hip under a macro, mlp_f16.hip is mlp_bf16.hip --: every
     # translation unit depends on every file that can be included)
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc", ".py")) or (h.endswith(".hip") and h not in SOURCES)]
-    includes = {"mlp_f16.hip": ["mlp_bf16.hip"], "mlp_f16_g2.hip": ["mlp_bf16_g2.hip"],
+    includes = {"mlp_f16.hip": ["mlp_bf16.hip"], "mlp_f16_g2.hip": ["mlp_bf16_g2.hip"], "mlp_f16_g2e.hip": ["mlp_bf16_g2e.hip"],
                 "mlp_f32_train_rec.hip": ["mlp_f32_train.hip"], "mlp_f32_train_recp.hip": ["mlp_f32_train.hip"]}
     hdrs += [os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
     objs, todo = [], []

@@ -1244,10 +1244,15 @@ if __name__ == "__main__":
                 with open(os.path.join(outdir, "mlp_f16_g2_body_d%d.gen.inc" % depth_head), "w") as f:
                     f.write(text.replace("v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16").replace("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32"))
             nlines = len(g.out)
-        # the fused body (encoder inside the kernel): bf16 rows (the fp16 tier's rows keep safe_sin's exact remainder: not generated)
+        # the fused body (encoder inside the kernel)
         g, blocks, NK = generate(depth_head, 0, fused=True)
+        text = "".join('"%s\\n"\n' % x for x in g.out)
         with open(os.path.join(outdir, "mlp_bf16_g2e_body_d%d.gen.inc" % depth_head), "w") as f:
-            f.write("".join('"%s\\n"\n' % x for x in g.out))
+            f.write(text)
+        # ... and its fp16 twin (mlp_f16_g2e.hip): the MFMA, the re-pack AND the encoder's packing on the f16 forms (since round 5 the fp16
+        # rows take the bf16 rows' one-fma remainder: rays_encode.hip encode_kernel, KIND != 0)
+        with open(os.path.join(outdir, "mlp_f16_g2e_body_d%d.gen.inc" % depth_head), "w") as f:
+            f.write(text.replace("v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16").replace("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32"))
     with open(os.path.join(outdir, "mlp_bf16_g2_tables.gen.inc"), "w") as f:
         f.write("\n".join(tables(blocks)) + "\n")
     total_pieces = sum(npw_of(d["chunk"]) for d in real)

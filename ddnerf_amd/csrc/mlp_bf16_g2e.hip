@@ -11,6 +11,26 @@
 
 #include "mlp_bf16_g2_tables.gen.inc"
 
+// G2E_HALF (mlp_f16_g2e.hip compiles this file a second time with it): the fp16 tier's fused kernel -- the body generated on the f16 forms of the
+// MFMA and of the two conversions (re-pack, encoder), the ray table's view-direction row in fp16 (ddnerf_ray_table, feat_dtype 2).
+#ifdef G2E_HALF
+#define G2E_KERNEL mlp_f16g2e_fwd_kernel
+#define G2E_SYM(x) ddnerf_encode_mlp_f16_##x
+#define G2E_G1_BYTES ddnerf_mlp_f16g1_packed_bytes
+#define G2E_STAMP_VAR g_f16g2e_stamps
+#define G2E_STAMP_SET ddnerf_debug_set_stamps_f16g2e
+#define G2E_BODY_D0 "mlp_f16_g2e_body_d0.gen.inc"
+#define G2E_BODY_D1 "mlp_f16_g2e_body_d1.gen.inc"
+#else
+#define G2E_KERNEL mlp_bf16g2e_fwd_kernel
+#define G2E_SYM(x) ddnerf_encode_mlp_bf16_##x
+#define G2E_G1_BYTES ddnerf_mlp_bf16g1_packed_bytes
+#define G2E_STAMP_VAR g_bf16g2e_stamps
+#define G2E_STAMP_SET ddnerf_debug_set_stamps_g2e
+#define G2E_BODY_D0 "mlp_bf16_g2e_body_d0.gen.inc"
+#define G2E_BODY_D1 "mlp_bf16_g2e_body_d1.gen.inc"
+#endif
+
 #define G2E_SLOT_BYTES (36 * 1024)
 #define G2E_LDS_BYTES (4 * G2E_SLOT_BYTES)
 #define G2E_TILE 512
@@ -31,12 +51,12 @@ struct G2EArgs {
 };
 
 #ifdef BF16_STAMP  // diagnostic build only (mlp_bf16_g2.hip's layout): six values per workgroup -- s_memtime / s_memrealtime around its tile loop, tiles done, entry
-__device__ unsigned long long *g_bf16g2e_stamps;
-DDN_EXPORT int ddnerf_debug_set_stamps_g2e(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bf16g2e_stamps), &p, sizeof(p)); }
+__device__ unsigned long long *G2E_STAMP_VAR;
+DDN_EXPORT int G2E_STAMP_SET(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(G2E_STAMP_VAR), &p, sizeof(p)); }
 #endif
 
 template <bool DEPTH_HEAD>
-__global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
+__global__ __launch_bounds__(256, 1) void G2E_KERNEL(G2EArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[G2E_LDS_BYTES];
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
@@ -61,14 +81,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
         const u32x4 sst = {srs.x, srs.y, (unsigned long)tile + grid < (unsigned long)a.ntiles ? srs.z : 0u, srs.w};
         if constexpr (DEPTH_HEAD) {
             asm volatile(
-#include "mlp_bf16_g2e_body_d1.gen.inc"
+#include G2E_BODY_D1
                 :
                 : "s"(srs), "s"(rrs), "s"(plo), "s"(phi), "s"(lds0), "s"(wave), "s"(tile), "s"(grid), "s"(tile0), "s"(trs), "s"(yrs), "s"(s1),
                   "s"(magic), "s"(nmax), "s"(d64), "s"(tab), "s"(sst)
                 : G2E_CLOBBERS);
         } else {
             asm volatile(
-#include "mlp_bf16_g2e_body_d0.gen.inc"
+#include G2E_BODY_D0
                 :
                 : "s"(srs), "s"(rrs), "s"(plo), "s"(phi), "s"(lds0), "s"(wave), "s"(tile), "s"(grid), "s"(tile0), "s"(trs), "s"(yrs), "s"(s1),
                   "s"(magic), "s"(nmax), "s"(d64), "s"(tab), "s"(sst)
@@ -83,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
 #ifdef BF16_STAMP
     {
         const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long *sp = g_bf16g2e_stamps;
+        unsigned long long *sp = G2E_STAMP_VAR;
         if (sp && threadIdx.x == 0) {
             sp[6 * blockIdx.x + 0] = st_t0;
             sp[6 * blockIdx.x + 1] = st_r0;
@@ -100,14 +120,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16g2e_fwd_kernel(G2EArgs a) {
 #define G2E_MAX_LAUNCH (1L << 22)
 
 // scratch the forward needs: one row area per workgroup of the persistent grid
-DDN_EXPORT size_t ddnerf_encode_mlp_bf16_scratch_bytes(void) { return (size_t)ddn_cu_count() * G2E_SCRATCH_PER_WG; }
+DDN_EXPORT size_t G2E_SYM(scratch_bytes)(void) { return (size_t)ddn_cu_count() * G2E_SCRATCH_PER_WG; }
 
-extern "C" size_t ddnerf_mlp_bf16g1_packed_bytes(int depth_head);
+extern "C" size_t G2E_G1_BYTES(int depth_head);
 
 // rays are given as their table (ddnerf_ray_table); t_vals [n, S + 1]; packed: the image of ddnerf_mlp_bf16_pack; raw [n * S, 4 | 6].
 // Cone rays only, S a multiple of 64 (a group of 64 samples lies on one ray), n * S <= 2^22: DDNERF_E_RANGE otherwise -- the caller
 // then runs ddnerf_encode + ddnerf_mlp_bf16_forward, which produce the same bits.
-DDN_EXPORT int ddnerf_encode_mlp_bf16_forward(const void *ray_table, const float *t_vals, const void *packed, int depth_head, float *raw,
+DDN_EXPORT int G2E_SYM(forward)(const void *ray_table, const float *t_vals, const void *packed, int depth_head, float *raw,
                                               int n, int S, void *scratch, ddnerf_stream_t stream) {
     DDN_REQUIRE(ray_table && t_vals && packed && raw && scratch, DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && S > 0, DDNERF_E_ARG);
@@ -118,13 +138,13 @@ DDN_EXPORT int ddnerf_encode_mlp_bf16_forward(const void *ray_table, const float
     const long ntiles = (M + G2E_TILE - 1) / G2E_TILE;
     const int n_cu = ddn_cu_count();
     const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
-    const size_t img = (ddnerf_mlp_bf16g1_packed_bytes(depth_head) + 255) & ~(size_t)255;   // (the two-group kernel's image inside the common one)
+    const size_t img = (G2E_G1_BYTES(depth_head) + 255) & ~(size_t)255;   // (the two-group kernel's image inside the common one)
     const unsigned d64 = (unsigned)(S / 64);
     G2EArgs a{t_vals, (const float *)ray_table, (const char *)packed + img, raw, (char *)scratch, M, ntiles, (unsigned)n, (unsigned)(S + 1),
               (unsigned)(((1ull << 31) + d64 - 1) / d64), d64};
     if (depth_head)
-        hipLaunchKernelGGL(mlp_bf16g2e_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(G2E_KERNEL<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(mlp_bf16g2e_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(G2E_KERNEL<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return ddn_launch_status();
 }

@@ -107,14 +107,28 @@ __global__ void pack_first_cycle_kernel(const float *__restrict__ ro, const floa
     t_vals[idx] = t;
 }
 
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
+    return __builtin_bit_cast(unsigned short, b);
+}
+// 16-bit feature rows: KIND 1 = bf16, KIND 2 = fp16 (the fp16 MLP tier: 11 significant bits; |features| <= 1 and the view direction's
+// components are far inside fp16's range, tiny damped values go through its subnormals or to zero: absolute error < 6e-8)
+template <int KIND>
+__device__ __forceinline__ unsigned short f32_to_h16(float f) {
+    if constexpr (KIND == 2) return __builtin_bit_cast(unsigned short, (_Float16)f);  // round-to-nearest-even
+    else return f32_to_bf16(f);
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // The per-RAY table of the fused encoder + MLP kernel (mlp_bf16_g2e.hip): what encode_kernel<1> derives from a packed ray row once
 // per sample (phase 1: d^2, the null-space factor 1 - d^2 / |d|^2 of lift_gaussian, general_utils/math_utils.py:34-54) or once per
 // block (phase 1b: the view directions' positional encoding, general_utils/nerf_helpers.py:127-171), once per ray: 16 floats
-// [o 0:3 | d 3:6 | radius^2 6 | d^2 7:10 | 1 - d^2/|d|^2 10:13 | 0 0 0], then the ray's 32 view-direction columns as a bf16 row in
+// [o 0:3 | d 3:6 | radius^2 6 | d^2 7:10 | 1 - d^2/|d|^2 10:13 | 0 0 0], then the ray's 32 view-direction columns as a bf16 / fp16 row in
 // MFMA k-order (the same arithmetic, operation for operation: the fused kernel's outputs equal the two-launch path's bit for bit).
 // ---------------------------------------------------------------------------------------------------
 #define DDN_RAY_TABLE_FLOATS 32
+template <int KIND>   // 1: the view-direction row as bf16, 2: as fp16 (the two 16-bit MLP tiers)
 __device__ __forceinline__ void ray_table_row(const float *__restrict__ r, float *__restrict__ t) {
     const float d0 = r[3], d1 = r[4], d2 = r[5];
     const float q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
@@ -141,26 +155,32 @@ __device__ __forceinline__ void ray_table_row(const float *__restrict__ r, float
     }
     unsigned short *row = (unsigned short *)(t + 16);
 #pragma unroll
-    for (int p = 0; p < 32; ++p) row[p] = __builtin_bit_cast(unsigned short, (__bf16)dirv[korder32(p)]);
+    for (int p = 0; p < 32; ++p) row[p] = f32_to_h16<KIND>(dirv[korder32(p)]);
 }
 
+template <int KIND>
 __global__ void ray_table_kernel(const float *__restrict__ rays, int n, float *__restrict__ table) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ray_table_row(rays + 12 * (size_t)i, table + DDN_RAY_TABLE_FLOATS * (size_t)i);
+    if (i < n) ray_table_row<KIND>(rays + 12 * (size_t)i, table + DDN_RAY_TABLE_FLOATS * (size_t)i);
 }
 
 DDN_EXPORT size_t ddnerf_ray_table_bytes(int n) { return (size_t)(n > 0 ? n : 0) * DDN_RAY_TABLE_FLOATS * sizeof(float); }
-DDN_EXPORT int ddnerf_ray_table(const float *rays, int n, void *table, ddnerf_stream_t stream) {
+DDN_EXPORT int ddnerf_ray_table(const float *rays, int n, int feat_dtype, void *table, ddnerf_stream_t stream) {
     DDN_REQUIRE(rays && table, DDNERF_E_ARG);
     DDN_REQUIRE(n > 0, DDNERF_E_ARG);
+    DDN_REQUIRE(feat_dtype == 1 || feat_dtype == 2, DDNERF_E_RANGE);
     DDN_REQUIRE(ddn_aligned(table, 128), DDNERF_E_ALIGN);
-    hipLaunchKernelGGL(ray_table_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, rays, n, (float *)table);
+    if (feat_dtype == 1)
+        hipLaunchKernelGGL(ray_table_kernel<1>, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, rays, n, (float *)table);
+    else
+        hipLaunchKernelGGL(ray_table_kernel<2>, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, rays, n, (float *)table);
     return ddn_launch_status();
 }
 
 // a1 + a2 + the ray table in ONE launch (the head of a one-chunk render pass on the fused bf16 path): pack_first_cycle_kernel without
 // jitter, whose j = 0 thread also writes its ray's table row from the values it has just packed -- rays, t_vals and table bit for bit
 // those of ddnerf_pack_rays_first_cycle (t_rand = NULL) followed by ddnerf_ray_table.
+template <int KIND>
 __global__ void pack_first_cycle_table_kernel(const float *__restrict__ ro, const float *__restrict__ rd, const float *__restrict__ rad,
                                               float near_, float far_, const float *__restrict__ t_lin, float *__restrict__ rays,
                                               float *__restrict__ t_vals, float *__restrict__ table, int n, int nc, int lindisp) {
@@ -180,21 +200,25 @@ __global__ void pack_first_cycle_table_kernel(const float *__restrict__ ro, cons
         float *dst = rays + 12 * (size_t)i;
 #pragma unroll
         for (int k = 0; k < 12; ++k) dst[k] = r[k];
-        ray_table_row(r, table + DDN_RAY_TABLE_FLOATS * (size_t)i);
+        ray_table_row<KIND>(r, table + DDN_RAY_TABLE_FLOATS * (size_t)i);
     }
     t_vals[idx] = first_cycle_t(near_, far_, t_lin[j], lindisp);
 }
 
 DDN_EXPORT int ddnerf_pack_rays_first_cycle_table(const float *origins, const float *directions, const float *radii, float near_, float far_,
-                                                  const float *t_lin, float *rays, float *t_vals, void *table, int n, int nc, int lindisp,
-                                                  ddnerf_stream_t stream) {
+                                                  const float *t_lin, float *rays, float *t_vals, int feat_dtype, void *table, int n, int nc,
+                                                  int lindisp, ddnerf_stream_t stream) {
     DDN_REQUIRE(origins && directions && radii && t_lin && rays && t_vals && table, DDNERF_E_ARG);
     DDN_REQUIRE(n > 0 && nc > 0, DDNERF_E_ARG);
-    DDN_REQUIRE(lindisp >= 0 && lindisp <= 2, DDNERF_E_RANGE);
+    DDN_REQUIRE(lindisp >= 0 && lindisp <= 2 && (feat_dtype == 1 || feat_dtype == 2), DDNERF_E_RANGE);
     DDN_REQUIRE(ddn_aligned(table, 128), DDNERF_E_ALIGN);
     size_t total = (size_t)n * (nc + 1);
-    hipLaunchKernelGGL(pack_first_cycle_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, origins,
-                       directions, radii, near_, far_, t_lin, rays, t_vals, (float *)table, n, nc, lindisp);
+    if (feat_dtype == 1)
+        hipLaunchKernelGGL(pack_first_cycle_table_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, origins,
+                           directions, radii, near_, far_, t_lin, rays, t_vals, (float *)table, n, nc, lindisp);
+    else
+        hipLaunchKernelGGL(pack_first_cycle_table_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, origins,
+                           directions, radii, near_, far_, t_lin, rays, t_vals, (float *)table, n, nc, lindisp);
     return ddn_launch_status();
 }
 
@@ -309,18 +333,6 @@ __device__ __forceinline__ float safe_sin_t(float x) {
     const float T = 314.159271f;
     const float xr = (fabsf(x) < T) ? x : remainder_pos(x, T);
     return fast_sin(xr);
-}
-
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
-    return __builtin_bit_cast(unsigned short, b);
-}
-// 16-bit feature rows: KIND 1 = bf16, KIND 2 = fp16 (the fp16 MLP tier: 11 significant bits; |features| <= 1 and the view direction's
-// components are far inside fp16's range, tiny damped values go through its subnormals or to zero: absolute error < 6e-8)
-template <int KIND>
-__device__ __forceinline__ unsigned short f32_to_h16(float f) {
-    if constexpr (KIND == 2) return __builtin_bit_cast(unsigned short, (_Float16)f);  // round-to-nearest-even
-    else return f32_to_bf16(f);
 }
 
 #ifndef ENC_SPB
@@ -455,8 +467,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
             damp[k] = BF16 ? fast_exp_neg(-0.5f * yv) : enc_exp_neg(-0.5f * yv);   // :149  (yv >= 0)
             ys[k] = y;
             yc[k] = y + 1.57079637f;                                          // :143  y + 0.5*fp32(pi)
-            if constexpr (KIND == 1) {
-                // bf16 rows (fp16 rows keep the exact recipe: that tier meets 1e-4 on seeded weights and 2e-4 on trained ones): torch.remainder(x, T) as x - floor(x / T) T -- one fma, EXACT whenever the quotient is right (the true
+            if constexpr (KIND != 0) {
+                // 16-bit rows (round 5: fp16 rows too -- that tier is no parity tier, it misses 1e-4 on trained weights whatever the remainder --,
+                // so that both 16-bit tiers share ONE recipe with the encoder inside their MLP kernels): torch.remainder(x, T) as x - floor(x / T) T -- one fma, EXACT whenever the quotient is right (the true
                 // remainder is representable); a quotient off by one near a multiple of T, and |x| < T with x < 0 (where the reference
                 // leaves x alone), move the argument by T = 100 pi + 5.6e-6: 5.6e-6 in the sine; the reference's own rounding of its
                 // `fmod + T` for negative x (<= 1.5e-5) is not reproduced.  <= 2e-5 in all, 1/200 of a bf16 ulp at 1 -- and no compare,
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ r
                 big |= !(fabsf(ys[k]) < T) || !(fabsf(yc[k]) < T);
             }
         }
-        if constexpr (KIND != 1) {
+        if constexpr (KIND == 0) {
             if (__builtin_amdgcn_ballot_w64(big) != 0) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {

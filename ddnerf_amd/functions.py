@@ -131,7 +131,7 @@ def needs_grad(net):
 
 def encode_mlp_bf16(table, t_vals, net):
     """models/models.py:117-142 in one launch (bf16 tier, inference): ray table [n,32] + fenceposts [n,S+1] -> raw [n*S,4|6]"""
-    return ops.encode_mlp_bf16_forward(table, t_vals, _packed_weights(net), net.depth_head)
+    return ops.encode_mlp_bf16_forward(table, t_vals, _packed_weights(net), net.depth_head, kind=net.mlp_dtype)
 
 
 def mlp_rays(feat, dirs, S, net):

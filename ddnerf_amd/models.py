@@ -53,7 +53,7 @@ class TorchRng:
 import os as _os
 
 FUSE_RENDER = _os.environ.get("DDNERF_FUSE_RENDER", "1") != "0"
-# bf16 tier: run_network (models/models.py:117-142) as ONE launch, the encoder inside the MLP kernel (ops.encode_mlp_bf16_forward;
+# bf16 and fp16 tiers: run_network (models/models.py:117-142) as ONE launch, the encoder inside the MLP kernel (ops.encode_mlp_bf16_forward;
 # bit-identical to encode + MLP).  "all" both passes, "fine" the fine pass only, "0" never.
 FUSE_ENCODER = _os.environ.get("DDNERF_FUSE_ENCODER", "all")
 # fp32 / x3 tiers, inference: the view-direction columns once per RAY (ops.encode_rays + mlp_*_forward_rays), as the reference computes them
@@ -266,19 +266,19 @@ class GeneralMipNerfModel(torch.nn.Module):
         pend = getattr(self, "_first_pending", None)
         first = pend is not None and pend[0].data_ptr() == ray_batch.data_ptr() and pend[1].data_ptr() == t_vals.data_ptr()
         n, S = t_vals.shape[0], t_vals.shape[1] - 1
-        if (kind == "bf16" and shape == "cone" and FUSE_ENCODER != "0" and (FUSE_ENCODER == "all" or not first)
+        if (kind in ("bf16", "fp16") and shape == "cone" and FUSE_ENCODER != "0" and (FUSE_ENCODER == "all" or not first)
                 and ops.encode_mlp_bf16_supported(S, n * S) and not F.needs_grad(network)):
             # the fused kernel: the encoded rows never exist; a per-RAY table (built once per ray batch, by the launch that packs the rays
             # when this is the coarse pass of a one-chunk batch) carries what the encoder derives from a ray
             if first:
                 self._first_pending = None
                 rays, t0, ro, rd, rad, t_lin, lindisp = pend
-                table = ops.pack_rays_first_cycle_table(ro, rd, rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin, lindisp, out=(rays, t0))[2]
+                table = ops.pack_rays_first_cycle_table(ro, rd, rad, self.cfg.dataset.near, self.cfg.dataset.far, t_lin, lindisp, out=(rays, t0), kind=kind)[2]
             else:
                 if pend is not None:
                     self._flush_first_pending()
                 held = getattr(self, "_ray_table", None)
-                table = held[1] if held is not None and held[0] is ray_batch else ops.ray_table(ray_batch)
+                table = held[1] if held is not None and held[0] is ray_batch else ops.ray_table(ray_batch, kind)
             self._ray_table = (ray_batch, table)
             raw = F.encode_mlp_bf16(table, t_vals, network)
             return raw.reshape(n, S, raw.shape[-1])

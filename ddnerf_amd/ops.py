@@ -234,16 +234,16 @@ def train_loss_backward(rgb0, rgb1, target, n_dp, c0, c1, c_dp, g):
     return g0, g1, gd
 
 
-def ray_table(rays):
-    """rays [n,12] -> the fused kernel's per-ray table [n,32] (fp32 words: 16 floats, then the ray's view-direction row as 32 bf16)"""
+def ray_table(rays, kind="bf16"):
+    """rays [n,12] -> the fused kernels' per-ray table [n,32] (fp32 words: 16 floats, then the ray's view-direction row as 32 bf16 / fp16)"""
     rays = _f32c(rays, "rays")
     n = rays.shape[0]
     table = torch.empty((n, 32), dtype=torch.float32, device=rays.device)
-    _lib.check(_lib.lib().ddnerf_ray_table(_ptr(rays), n, _ptr(table), _stream()), "ddnerf_ray_table")
+    _lib.check(_lib.lib().ddnerf_ray_table(_ptr(rays), n, FEAT_KINDS[kind][0], _ptr(table), _stream()), "ddnerf_ray_table")
     return table
 
 
-def pack_rays_first_cycle_table(ray_origins, ray_directions, ray_rad, near, far, t_lin, lindisp=False, out=None):
+def pack_rays_first_cycle_table(ray_origins, ray_directions, ray_rad, near, far, t_lin, lindisp=False, out=None, kind="bf16"):
     """pack_rays_first_cycle (no jitter) + ray_table in ONE launch -> (rays [n,12], t_vals [n,nc+1], table [n,32]); `out` = (rays, t_vals)
     tensors to fill (handed out earlier by GeneralMipNerfModel.get_rays_batches)"""
     o = _f32c(ray_origins.reshape(-1, 3), "origins")
@@ -256,7 +256,7 @@ def pack_rays_first_cycle_table(ray_origins, ray_directions, ray_rad, near, far,
     rays, t_vals = out
     table = torch.empty((n, 32), dtype=torch.float32, device=o.device)
     _lib.check(_lib.lib().ddnerf_pack_rays_first_cycle_table(_ptr(o), _ptr(d), _ptr(r), float(near), float(far), _ptr(t_lin), _ptr(rays),
-                                                             _ptr(t_vals), _ptr(table), n, nc, int(lindisp), _stream()),
+                                                             _ptr(t_vals), FEAT_KINDS[kind][0], _ptr(table), n, nc, int(lindisp), _stream()),
                "ddnerf_pack_rays_first_cycle_table")
     return rays, t_vals, table
 
@@ -268,9 +268,9 @@ def encode_mlp_bf16_supported(S, M, cylinder=False):
     return (not cylinder) and S % 64 == 0 and M <= (1 << 22)
 
 
-def encode_mlp_bf16_forward(table, t_vals, packed, depth_head):
-    """models/models.py:117-142 as one launch (bf16 tier): cast_rays + integrated_pos_enc + view directions + the MLP; t_vals [n,S+1]
-    -> raw [n*S, 4|6], bit for bit encode(kind="bf16") + mlp_bf16_forward"""
+def encode_mlp_bf16_forward(table, t_vals, packed, depth_head, kind="bf16"):
+    """models/models.py:117-142 as one launch (bf16 tier; kind="fp16": the fp16 tier's twin): cast_rays + integrated_pos_enc + view directions +
+    the MLP; t_vals [n,S+1] -> raw [n*S, 4|6], bit for bit encode(kind=kind) + mlp_bf16_forward / mlp_f16_forward"""
     t_vals = _f32c(t_vals, "t_vals")
     n, S = t_vals.shape[0], t_vals.shape[1] - 1
     M = n * S
@@ -281,8 +281,8 @@ def encode_mlp_bf16_forward(table, t_vals, packed, depth_head):
         scratch = _FUSED_SCRATCH[key] = torch.empty(_lib.lib().ddnerf_encode_mlp_bf16_scratch_bytes(), dtype=torch.uint8, device=t_vals.device)
 
     def launch():
-        _lib.check(_lib.lib().ddnerf_encode_mlp_bf16_forward(_ptr(table), _ptr(t_vals), _ptr(packed), int(depth_head), _ptr(raw), n, S,
-                                                             _ptr(scratch), _stream()), "ddnerf_encode_mlp_bf16_forward")
+        fn = "ddnerf_encode_mlp_%s_forward" % {"bf16": "bf16", "fp16": "f16"}[kind]
+        _lib.check(getattr(_lib.lib(), fn)(_ptr(table), _ptr(t_vals), _ptr(packed), int(depth_head), _ptr(raw), n, S, _ptr(scratch), _stream()), fn)
 
     if MLP_LAUNCH_HOOK is not None:
         MLP_LAUNCH_HOOK(M, launch)

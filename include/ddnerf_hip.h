@@ -138,21 +138,26 @@ int ddnerf_mlp_bf16g2_forward(const void *feat, const void *packed, int depth_he
  * two-group kernel above carries the encoder in the vector-ALU gaps of its MFMA stream (gen_bf16_g2.py, Gen(fused=True)).
  *   ddnerf_ray_table: rays [n,12] (ddnerf_pack_rays) -> one 128-byte row per RAY: origin, direction, radius^2, d^2, 1 - d^2/|d|^2 as
  *     fp32 (general_utils/math_utils.py:34-54), then the ray's 32 view-direction columns (general_utils/nerf_helpers.py:127-171) as a
- *     bf16 row in k-order; table: ddnerf_ray_table_bytes(n) bytes, 128-byte aligned.
+ *     16-bit row in k-order (feat_dtype 1: bf16, 2: fp16); table: ddnerf_ray_table_bytes(n) bytes, 128-byte aligned.
  *   ddnerf_encode_mlp_bf16_forward: t_vals [n,S+1] -> raw [n*S, 4|6]; packed = the image of ddnerf_mlp_bf16_pack; scratch =
  *     ddnerf_encode_mlp_bf16_scratch_bytes() bytes the launch may overwrite (its workgroups' private row areas).  Cone rays, S a
  *     multiple of 64, n*S <= 2^22: otherwise DDNERF_E_RANGE, and the caller runs ddnerf_encode(feat_dtype 1) + ddnerf_mlp_bf16_forward,
  *     whose outputs these are BIT FOR BIT. */
 size_t ddnerf_ray_table_bytes(int n);
-int ddnerf_ray_table(const float *rays, int n, void *table, ddnerf_stream_t stream);
+int ddnerf_ray_table(const float *rays, int n, int feat_dtype, void *table, ddnerf_stream_t stream);   /* feat_dtype: 1 bf16, 2 fp16 (the row's 16-bit half) */
 /* a1 + a2 + the table in ONE launch (the head of a one-chunk render pass): ddnerf_pack_rays_first_cycle with t_rand = NULL followed by
  * ddnerf_ray_table, bit for bit. */
 int ddnerf_pack_rays_first_cycle_table(const float *origins, const float *directions, const float *radii, float near_, float far_,
-                                       const float *t_lin, float *rays, float *t_vals, void *table, int n, int nc, int lindisp,
+                                       const float *t_lin, float *rays, float *t_vals, int feat_dtype, void *table, int n, int nc, int lindisp,
                                        ddnerf_stream_t stream);
 size_t ddnerf_encode_mlp_bf16_scratch_bytes(void);
 int ddnerf_encode_mlp_bf16_forward(const void *ray_table, const float *t_vals, const void *packed, int depth_head, float *raw, int n, int S,
                                    void *scratch, ddnerf_stream_t stream);
+/* ... the fp16 tier's twin (table with feat_dtype 2, packed = the image of ddnerf_mlp_f16_pack): bit for bit ddnerf_encode(feat_dtype = 2) +
+ * ddnerf_mlp_f16_forward */
+size_t ddnerf_encode_mlp_f16_scratch_bytes(void);
+int ddnerf_encode_mlp_f16_forward(const void *ray_table, const float *t_vals, const void *packed, int depth_head, float *raw, int n, int S,
+                                  void *scratch, ddnerf_stream_t stream);
 
 /* fp16-MFMA variant: the two bf16 kernels above built on v_mfma_f32_16x16x32_f16 / v_cvt_pk_f16_f32 (same rate, same registers, same
  * images, same schedule); feat: fp16 [M,128] in the same k-order, as written by ddnerf_encode(feat_dtype=2).  fp16 keeps 11

@@ -1,4 +1,4 @@
-"""The fused encoder + MLP kernel of the bf16 tier (ddnerf_encode_mlp_bf16_forward, mlp_bf16_g2e.hip: run_network of
+"""The fused encoder + MLP kernel of the bf16 tier and its fp16 twin (ddnerf_encode_mlp_bf16_forward / _f16_, mlp_bf16_g2e.hip: run_network of
 models/models.py:117-142 as ONE launch -- cast_rays, integrated_pos_enc, the view directions' encoding and the network) against the two
 launches it replaces, ddnerf_encode(feat_dtype = 1) + ddnerf_mlp_bf16_forward: BIT FOR BIT, on BASELINE's fine and coarse pass, ragged
 last tiles, several tiles per workgroup (the steady state: the encoder of the NEXT tile rides in the MFMA gaps of layers 6 - 8),
@@ -40,10 +40,10 @@ def _inputs(ops, kind, n, S, seed, sorted_random=True):
     return rays, t.float().contiguous()
 
 
-def _both(ops, rays, t, packed, depth):
-    feat = ops.encode(rays, t, kind="bf16")
-    want = ops.mlp_bf16_forward(feat, packed, depth)
-    got = ops.encode_mlp_bf16_forward(ops.ray_table(rays), t, packed, depth)
+def _both(ops, rays, t, packed, depth, kind="bf16"):
+    feat = ops.encode(rays, t, kind=kind)
+    want = {"bf16": ops.mlp_bf16_forward, "fp16": ops.mlp_f16_forward}[kind](feat, packed, depth)
+    got = ops.encode_mlp_bf16_forward(ops.ray_table(rays, kind), t, packed, depth, kind=kind)
     torch.cuda.synchronize()
     return got, want
 
@@ -54,22 +54,24 @@ def _assert_same(got, want, what):
     assert bool(same.all()), (what, int((~same).any(dim=1).sum()), int((~same).any(dim=1).nonzero()[0]), float((got - want).abs().nan_to_num().max()))
 
 
-def test_ray_table_repeats_the_encoder(ops):
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
+def test_ray_table_repeats_the_encoder(ops, kind):
     """the table's view-direction row IS columns 96..127 of every encoded row of that ray; its fp32 words are the packed ray's"""
     rays, t = _inputs(ops, "blender", 300, 64, 3)
-    tab = ops.ray_table(rays)
-    feat = ops.encode(rays, t, kind="bf16").view(300, 64, 128)
-    dirs = tab.view(torch.bfloat16).view(300, 64)[:, 32:]
+    tab = ops.ray_table(rays, kind)
+    feat = ops.encode(rays, t, kind=kind).view(300, 64, 128)
+    dirs = tab.view(torch.bfloat16 if kind == "bf16" else torch.float16).view(300, 64)[:, 32:]
     assert torch.equal(dirs.view(torch.int16), feat[:, 0, 96:].contiguous().view(torch.int16))
     assert torch.equal(dirs.view(torch.int16), feat[:, 63, 96:].contiguous().view(torch.int16))
     assert torch.equal(tab[:, 0:6], rays[:, 0:6]) and torch.equal(tab[:, 6], rays[:, 6] * rays[:, 6])
     assert torch.equal(tab[:, 7:10], rays[:, 3:6] * rays[:, 3:6])
 
 
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
 @pytest.mark.parametrize("depth", [False, True])
-def test_fused_kernel_bit_identical_to_encode_then_mlp(ops, depth):
+def test_fused_kernel_bit_identical_to_encode_then_mlp(ops, depth, kind):
     flat = _flat(depth, 12, 20.0)
-    packed = ops.mlp_bf16_pack(flat, depth)
+    packed = {"bf16": ops.mlp_bf16_pack, "fp16": ops.mlp_f16_pack}[kind](flat, depth)
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     cases = [("blender", 4096, 128, True),          # BASELINE's fine pass: four tiles per workgroup
              ("blender", 4096, 64, False),          # its coarse pass: two
@@ -78,10 +80,10 @@ def test_fused_kernel_bit_identical_to_encode_then_mlp(ops, depth):
              ("blender", 7, 192, True),             # S / 64 = 3: groups per ray not a power of two
              ("llff", 1000, 128, True),             # NDC rays (near 0: means near zero, wide Gaussians)
              ("real360", 2 * n_cu * 4 + 5, 128, True)]   # every workgroup two tiles and a few a third, ragged
-    for kind, n, S, rnd in cases:
-        rays, t = _inputs(ops, kind, n, S, n + S, rnd)
-        got, want = _both(ops, rays, t, packed, depth)
-        _assert_same(got, want, (kind, n, S, depth))
+    for rkind, n, S, rnd in cases:
+        rays, t = _inputs(ops, rkind, n, S, n + S, rnd)
+        got, want = _both(ops, rays, t, packed, depth, kind)
+        _assert_same(got, want, (kind, rkind, n, S, depth))
         assert bool(torch.isfinite(want).all())
 
 
@@ -109,8 +111,9 @@ def test_fused_kernel_launch_after_launch(ops):
         _assert_same(got, want, it)
 
 
+@pytest.mark.parametrize("tier", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", ["fullsize_cfg2_dd_blender_4096_64x128", "fullsize_cfg3_dd_llff_4096_64x128", "fullsize_trained_dd_blender_4096_64x128"])
-def test_run_iter_is_the_same_with_the_encoder_inside_or_outside_the_mlp_kernel(name, monkeypatch):
+def test_run_iter_is_the_same_with_the_encoder_inside_or_outside_the_mlp_kernel(name, tier, monkeypatch):
     """The whole render pass of the bf16 tier at BASELINE size: DDNERF_FUSE_ENCODER = all (default: both passes one launch each), fine (the
     coarse pass keeps its encode launch) and 0 (two launches per pass) give the SAME output dict, bit for bit -- the kernels are bit-identical, so
     every downstream value (sampler, compositing, dp loss, records) is too.  Also as an image of several chunks (the per-chunk ray table)."""
@@ -124,7 +127,7 @@ def test_run_iter_is_the_same_with_the_encoder_inside_or_outside_the_mlp_kernel(
     def run(mode, chunk=None):
         monkeypatch.setattr(M, "FUSE_ENCODER", mode)
         model = build_model(c)
-        model.cfg.nerf["mlp_dtype"] = "bf16"
+        model.cfg.nerf["mlp_dtype"] = tier
         model._set_mlp_dtype()
         model.eval()
         if chunk:
