@@ -50,7 +50,7 @@ CONFIGS = {
 }
 KERNEL_SOURCES = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2e_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"],
                   "x3": ["mlp_x3_fwd.hip", "mlp_x3_fwd_rays.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
-                  "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
+                  "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_f16_g2e.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_f16_g2e_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}
 
 
 def parse(argv=None):
@@ -771,7 +771,7 @@ def main(argv=None):
                 roof["view_dirs_per_ray"] = bool(_m.RAY_DIRS and _o.mlp_rays_supported(args.fine, M_fine))
                 if roof["view_dirs_per_ray"]:
                     roof["kernel"] = "mlp_%s_fwd_rays_kernel<fine> (view-direction columns from a per-ray table; %d samples/launch)" % (args.mlp, M_fine)
-            if args.mlp == "bf16":
+            if args.mlp in ("bf16", "fp16"):
                 from ddnerf_amd import models as _m
                 from ddnerf_amd import ops as _o
 
@@ -780,7 +780,7 @@ def main(argv=None):
                 if fused:
                     # (the launch that is timed also ENCODES its samples -- cast_rays + integrated_pos_enc, models/models.py:117-142 -- and
                     # the unfused path's encode launch is gone from the step; `achieved` / `frac` still count the MLP's FLOP only)
-                    roof["kernel"] = "mlp_bf16g2e_fwd_kernel<fine> (encoder inside the MLP kernel; %d samples/launch)" % M_fine
+                    roof["kernel"] = "mlp_%sg2e_fwd_kernel<fine> (encoder inside the MLP kernel; %d samples/launch)" % ({"bf16": "bf16", "fp16": "f16"}[args.mlp], M_fine)
             if args.mlp == "fp32" and (args.rays, args.fine) == (4096, 128) and not args.no_clock and cfg.nerf.type == "DDNerfModel":
                 roof["clock"] = f32_in_kernel_clock(model, device)
             if args.mlp == "bf16" and (args.rays, args.fine) == (4096, 128) and not args.no_clock:

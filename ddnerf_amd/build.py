@@ -25,6 +25,7 @@ SOURCES = {
     "mlp_f32_train.hip": [],
     "mlp_f32_train_rec.hip": [],
     "mlp_f32_train_recp.hip": [],
+    "mlp_f32_train_recf.hip": [],
     "mlp_f32_wgrad.hip": [],
     "mlp_x3_wgrad.hip": [],
     "mlp_x3_wgrad_packed.hip": [],
@@ -141,7 +142,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     # translation unit depends on every file that can be included)
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc", ".py")) or (h.endswith(".hip") and h not in SOURCES)]
     includes = {"mlp_f16.hip": ["mlp_bf16.hip"], "mlp_f16_g2.hip": ["mlp_bf16_g2.hip"], "mlp_f16_g2e.hip": ["mlp_bf16_g2e.hip"],
-                "mlp_f32_train_rec.hip": ["mlp_f32_train.hip"], "mlp_f32_train_recp.hip": ["mlp_f32_train.hip"]}
+                "mlp_f32_train_rec.hip": ["mlp_f32_train.hip"], "mlp_f32_train_recp.hip": ["mlp_f32_train.hip"], "mlp_f32_train_recf.hip": ["mlp_f32_train.hip"]}
     hdrs += [os.path.join(CSRC, "..", "..", "include", "ddnerf_hip.h"), __file__]
     objs, todo = [], []
     for src, extra in SOURCES.items():

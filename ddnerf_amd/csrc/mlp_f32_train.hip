@@ -164,6 +164,34 @@ __device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, siz
     return v;
 }
 __device__ __forceinline__ bool tile_positive(float w) { return (__builtin_bit_cast(unsigned, w) & 0x7fffu) != 0u; }
+#elif F32_REC == 3
+// Fourth build (mlp_f32_train_recf.hip, round 5): records in the SAME blocked layout that hold the fp32 VALUES -- element (row, sample m) at
+// word index ((m >> 4) * 2560 + row) * 16 + (m & 15) -- for the weight-gradient kernel that splits them into bf16 hi / lo while it builds
+// its MFMA fragments (ddnerf_mlp_x3_wgrad_blocked: the same split, the same products, bit-identical weight gradients).  What it buys: the
+// split was 3.5 vector-ALU instructions per element in kernels whose fp32 MFMA chain stops for every one of them (4 gaps x (12 + 4 x 14)
+// cycles per 32 x 32 tile of the forward, 3.3 % of its 8192 MFMA cycles; 2.7 % of the backward); the weight-gradient kernels wait for
+// HBM and have the vector ALU idle.
+#define F32_NAME(x) x##_recf
+typedef unsigned u32x4_rec __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned rec_word(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ void rec_word2(float x0, float x1, unsigned &w0, unsigned &w1) {
+    w0 = __builtin_bit_cast(unsigned, x0);
+    w1 = __builtin_bit_cast(unsigned, x1);
+}
+__device__ __forceinline__ size_t rec_base(int row0, size_t col, int h) { return ((col >> 4) * ACT_ROWS + row0 + 4 * h) * 16 + (col & 15); }
+__device__ __forceinline__ void store_tile_t(float *__restrict__ mat, size_t, int row0, size_t col, int h, const f32x16 &v) {
+    float *p = mat + rec_base(row0, col, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) TSTORE(v[r], p + tile_row(r, 0) * 16);
+}
+__device__ __forceinline__ f32x16 load_tile_t(const float *__restrict__ mat, size_t, int row0, size_t col, int h) {
+    const float *p = mat + rec_base(row0, col, h);
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = TLOAD(p + tile_row(r, 0) * 16);
+    return v;
+}
+__device__ __forceinline__ bool tile_positive(float a) { return a > 0.0f; }
 #else
 #define F32_NAME(x) x##_rec
 __device__ __forceinline__ unsigned rec_word(float x) {
@@ -224,7 +252,7 @@ __device__ __forceinline__ bool tile_positive(float a) { return a > 0.0f; }
 
 struct Recorder {
     static constexpr bool kActive = true;
-#if defined(F32_REC) && F32_REC == 1 && !defined(F32_EXP_NOQUADS)   // (F32_EXP_NOQUADS: diagnostic build with the 4-byte stores)
+#if defined(F32_REC) && (F32_REC == 1 || F32_REC == 3) && !defined(F32_EXP_NOQUADS)   // (F32_EXP_NOQUADS: diagnostic build with the 4-byte stores)
     static constexpr bool kQuads = true;   // hi/lo words: one word per value, four consecutive samples of a row = 16 contiguous bytes
     unsigned voff_t;                       // this lane's byte offset for a quad (mlp_f32_fwd.inc: the transposed read of the scratch)
 #else
@@ -256,7 +284,7 @@ struct Recorder {
 #endif
 #endif
     }
-#if F32_REC == 1 && !defined(F32_EXP_NOQUADS)
+#if (F32_REC == 1 || F32_REC == 3) && !defined(F32_EXP_NOQUADS)
     __device__ __forceinline__ void store_quad(int row0, int i, f32x4 x) {
         unsigned w0, w1, w2, w3;
         rec_word2(x.x, x.y, w0, w1);

@@ -39,9 +39,30 @@ __device__ __forceinline__ void xp_unpack(const u32x4 w0, const u32x4 w1, bf16x8
     hi = __builtin_bit_cast(bf16x8, h);
     lo = __builtin_bit_cast(bf16x8, l);
 }
+// 8 fp32 VALUES (k = 0..7 of one row of a blocked fp32 record) -> the same two fragments: hi = bf16(x), lo = bf16(x - hi), round to nearest
+// even -- the split the record-writing kernels computed before round 5 (mlp_f32_train.hip, rec_word2), instruction for instruction
+typedef float xp_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 xp_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void xp_split2(unsigned x0, unsigned x1, unsigned &h01, unsigned &l01) {
+    const float f0 = __builtin_bit_cast(float, x0), f1 = __builtin_bit_cast(float, x1);
+    h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((xp_f32x2){f0, f1}, xp_bf16x2));
+    const float hf0 = __builtin_bit_cast(float, h01 << 16), hf1 = __builtin_bit_cast(float, h01 & 0xffff0000u);
+    l01 = __builtin_bit_cast(unsigned, __builtin_convertvector((xp_f32x2){f0 - hf0, f1 - hf1}, xp_bf16x2));
+}
+__device__ __forceinline__ void xp_split(const u32x4 w0, const u32x4 w1, bf16x8 &hi, bf16x8 &lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    xp_split2(w0.x, w0.y, h0, l0);
+    xp_split2(w0.z, w0.w, h1, l1);
+    xp_split2(w1.x, w1.y, h2, l2);
+    xp_split2(w1.z, w1.w, h3, l3);
+    hi = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
+    lo = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
+}
 __device__ __forceinline__ float xp_value(unsigned w) {
     return __builtin_bit_cast(float, w & 0xffff0000u) + __builtin_bit_cast(float, w << 16);
 }
+// (by value: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 of the vector with this compiler)
+__device__ __forceinline__ float xp_f32(unsigned w) { return __builtin_bit_cast(float, w); }
 __device__ __forceinline__ float xp_hi16(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ float xp_lo16(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 
@@ -56,7 +77,14 @@ template <int ROWS> constexpr int xp_nslot() { return ROWS * 64 * 8 <= 160 * 102
 // 32-bit word holds bf16(row 2p) | bf16(row 2p + 1) << 16 of one sample, a record row is a row PAIR; every product is ONE MFMA.
 // Everything is the same kernel on half as many LDS rows (a lane's row is the low or the high half of its pair's words: one
 // v_perm_b32 selector per lane); a bias item sums both rows of its pair.
-template <int RT, int CT, int RG, int CG, bool BIAS, int NINA = 0, bool PAIRS = false>
+// RAW (round 5): the operands are blocked records of fp32 VALUES (mlp_f32_train_recf.hip): same layout, same transfers.  The hi / lo split
+// happens here, ONCE per value: when slot u + 1 has landed, the workgroup's threads convert it in place -- an item is one row's 8 samples
+// of a k-half (two 16-byte chunks of raw fp32 -> the chunk of their 8 bf16 hi parts and the chunk of their 8 lo parts, 24 vector-ALU
+// instructions, the split of mlp_f32_train.hip's rec_word2), the bias sums ride on the raw values -- while slot u feeds the MFMAs; a
+// fragment is then two ds_read_b128 and NO permute.  Per thread and slot: 2 items = 48 instructions (the word records' 48 permutes + 28 for
+// the bias sums); one slot less of transfers in flight (a slot must land an iteration earlier).  Splitting per fragment instead (each of a
+// row's 2 - 4 reading waves its own: 144 instructions per thread and slot) measured 330 against the word kernel's 279 us.
+template <int RT, int CT, int RG, int CG, bool BIAS, int NINA = 0, bool PAIRS = false, bool RAW = false>
 __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned *__restrict__ dT, const unsigned *__restrict__ aT,
                                                                   const unsigned *__restrict__ aT2, long M, long ld, int tiles_per_wg,
                                                                   float *__restrict__ slabs, float *__restrict__ bias_slabs) {
@@ -69,6 +97,8 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
     constexpr int NBI = NOPL * 4, MAXB = (NBI + THREADS - 1) / THREADS;  // bias items (LDS row, chunk) per slot / per thread
     static_assert(NOPL % 16 == 0 && NINAL % 16 == 0 && ROWS % 16 == 0, "whole 16-row transfers");
     static_assert((NS - 2) * IPW <= 63, "vmcnt range");
+    constexpr int NITEM = ROWS * 2, IPT = (NITEM + THREADS - 1) / THREADS;  // RAW: conversion items (LDS row, k-half) per slot / per thread
+    static_assert(!(RAW && PAIRS) && NS >= 4, "");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -126,17 +156,82 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
 #pragma unroll
         for (int u = 0; u < NS - 1; ++u) issue(u, u);
     }
+    // RAW: the in-place conversion of a landed slot.  Item (row, hf) -> LDS positions co (samples 8 hf .. + 3) and co ^ 16 (+ 4 .. + 7)
+    unsigned co[IPT];
+    float csum[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int item = k * THREADS + tid, row = item >> 1, hf = item & 1;
+        co[k] = (unsigned)(row * 64 + (((2 * hf) ^ ((row >> 2) & 3)) * 16));
+        csum[k] = 0.0f;
+    }
+    auto nv_of = [&](int u) {   // samples of slot u that exist (uniform)
+        const long nv_l = M - (tile0 * 2 + u) * 16;
+        return nv_l >= 16 ? 16 : (int)(nv_l > 0 ? nv_l : 0);
+    };
+    auto convert = [&](char *sbw, int nv) {
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int item = k * THREADS + tid, hf = item & 1;
+            if ((k + 1) * THREADS <= NITEM || item < NITEM) {
+                u32x4 w0 = *(const u32x4 *)(sbw + co[k]), w1 = *(const u32x4 *)(sbw + (co[k] ^ 16u));
+                if (nv < 16) {   // (a record's pad columns may hold anything, NaN included: zero in BOTH operands)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (8 * hf + e >= nv) w0[e] = 0u;
+                        if (8 * hf + 4 + e >= nv) w1[e] = 0u;
+                    }
+                }
+                if (BIAS && ((k + 1) * THREADS <= 2 * NOPL || item < 2 * NOPL))
+                    csum[k] += ((xp_f32(w0.x) + xp_f32(w0.y)) + (xp_f32(w0.z) + xp_f32(w0.w))) + ((xp_f32(w1.x) + xp_f32(w1.y)) + (xp_f32(w1.z) + xp_f32(w1.w)));
+                bf16x8 hi, lo;
+                xp_split(w0, w1, hi, lo);
+                *(bf16x8 *)(sbw + co[k]) = hi;
+                *(bf16x8 *)(sbw + (co[k] ^ 16u)) = lo;
+            }
+        }
+    };
+    if (RAW && nht > 0) {   // slot 0: landed, converted; the loop's first barrier publishes it
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        convert(lds_raw, nv_of(0));
+    }
     int rd = 0, wr = NS - 1;  // ring positions of slot u and of slot u + NS - 1
     for (int u = 0; u < nht; ++u) {
         // slot u has landed (this wave's share: all but the transfers of the NS-2 slots issued after it), for every wave; and
         // every wave is done with slot u-1, whose buffer the next transfers overwrite
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPW) : "memory");
+        // (RAW: slot u + 1 has landed, slot u is converted -- this thread's LDS writes are out --, every wave is done with slot u - 1)
+        if constexpr (RAW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 3) * IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue(u + NS - 1, wr);
         const char *sb = lds_raw + (size_t)rd * SLOT;
         rd = rd + 1 == NS ? 0 : rd + 1;
         wr = wr + 1 == NS ? 0 : wr + 1;
+        if constexpr (RAW) {
+            bf16x8 ah[RT], al[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const char *p = sb + (rg * RT + rt) * TILE_LR * 64;
+                ah[rt] = *(const bf16x8 *)(p + o0);
+                al[rt] = *(const bf16x8 *)(p + o1);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const char *p = sb + (NOPL + (cg * CT + ct) * TILE_LR) * 64;
+                const bf16x8 bh = *(const bf16x8 *)(p + o0), bl = *(const bf16x8 *)(p + o1);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {  // small terms first
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][ct], 0, 0, 0);
+                }
+            }
+            if (u + 1 < nht) convert(lds_raw + (size_t)rd * SLOT, nv_of(u + 1));   // (rd: already the ring position of slot u + 1)
+            continue;
+        }
         // samples of this slot that exist: 16, except in the last granule of a ragged M -- there the words of the samples >= M are
         // replaced by zeros in BOTH operands (a record's pad columns may hold anything, NaN included: 0 x NaN is NaN)
         const long nv_l = M - (tile0 * 2 + u) * 16;
@@ -209,7 +304,16 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 slab[(size_t)((rg * RT + rt) * 32 + tile_row(r, h)) * NIN + (cg * CT + ct) * 32 + i] = acc[rt][ct][r];
-    if (BIAS) {
+    if (BIAS && RAW) {
+        // conversion item (row, k-half) is owned by the same thread in every slot; the two halves of a row sit in adjacent lanes
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int item = k * THREADS + tid, row = item >> 1;
+            float s = csum[k];
+            s += __shfl_xor(s, 1);
+            if ((item & 1) == 0 && row < NOPL) bias_slabs[(size_t)blockIdx.x * NOP + row] = s;
+        }
+    } else if (BIAS) {
         // item (row, chunk) is owned by the same thread in every slot; the 4 chunks of a row sit in 4 adjacent lanes
 #pragma unroll
         for (int r = 0; r < MAXB; ++r) {
@@ -227,7 +331,7 @@ __global__ __launch_bounds__(64 * RG * CG) void wgrad_x3p_kernel(const unsigned 
 
 static int n_out_pad_of(int n_out) { return n_out > 128 ? 256 : (n_out > 32 ? 128 : 32); }
 
-template <bool PAIRS>
+template <bool PAIRS, bool RAW = false>
 static int wgrad_packed_impl(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used, long M, long ld,
                              float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
     DDN_REQUIRE(deltas && acts && dst && workspace, DDNERF_E_ARG);
@@ -255,10 +359,10 @@ static int wgrad_packed_impl(const void *deltas, int drow0, int n_out, const voi
         constexpr int ROWS_ = (32 * RT * RG + 32 * CT * CG) / RPW;                                                      \
         const size_t lds = (size_t)ROWS_ * 64 * xp_nslot<ROWS_>();                                                      \
         if (bias_slabs)                                                                                                 \
-            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, true, 0, PAIRS>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
+            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, true, 0, PAIRS, RAW>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
                                tiles_per_wg, slabs, bias_slabs);                                                        \
         else                                                                                                            \
-            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, false, 0, PAIRS>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
+            hipLaunchKernelGGL((wgrad_x3p_kernel<RT, CT, RG, CG, false, 0, PAIRS, RAW>), dim3(nwg), dim3(64 * RG * CG), lds, st, dT, aT, aT, M, ld, \
                                tiles_per_wg, slabs, bias_slabs);                                                        \
     } while (0)
     if (n_out_pad == 256) {
@@ -276,7 +380,7 @@ static int wgrad_packed_impl(const void *deltas, int drow0, int n_out, const voi
     return ddn_launch_status();
 }
 
-template <bool PAIRS>
+template <bool PAIRS, bool RAW = false>
 static int wgrad_packed_skip_impl(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld, float *dst,
                                   float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
     DDN_REQUIRE(deltas && acts && dst && dst_bias && workspace, DDNERF_E_ARG);
@@ -295,7 +399,7 @@ static int wgrad_packed_skip_impl(const void *deltas, int drow0, const void *act
     const unsigned *aA = (const unsigned *)acts + (size_t)(arow_a / RPW) * 16, *aB = (const unsigned *)acts + (size_t)(arow_b / RPW) * 16;
     constexpr int NIN = 352, ROWS = (256 + NIN) / RPW;
     float *slabs = workspace, *bias_slabs = workspace + (size_t)nwg * 256 * NIN;
-    hipLaunchKernelGGL((wgrad_x3p_kernel<1, 11, 8, 1, true, 96, PAIRS>), dim3(nwg), dim3(512), (size_t)ROWS * 64 * xp_nslot<ROWS>(), st, dT, aA, aB, M,
+    hipLaunchKernelGGL((wgrad_x3p_kernel<1, 11, 8, 1, true, 96, PAIRS, RAW>), dim3(nwg), dim3(512), (size_t)ROWS * 64 * xp_nslot<ROWS>(), st, dT, aA, aB, M,
                        ld, tiles_per_wg, slabs, bias_slabs);
     const int total = 256 * NIN, nb_w = (total + 63) / 64, nb_b = (256 + 63) / 64;
     const WgradReduceJob jw = {slabs, (size_t)256 * NIN, NIN, 256, NIN, NIN, 0, dst};
@@ -320,6 +424,20 @@ DDN_EXPORT int ddnerf_mlp_x3_wgrad_packed_skip(const void *deltas, int drow0, co
                                                float *dst, float *dst_bias, float *workspace, int max_workgroups,
                                                ddnerf_stream_t stream) {
     return wgrad_packed_skip_impl<false>(deltas, drow0, acts, arow_a, arow_b, M, ld, dst, dst_bias, workspace, max_workgroups, stream);
+}
+
+// The same two jobs on blocked records of fp32 VALUES (ddnerf_mlp_f32_forward_train_recf / _backward_data_recf write them): word index
+// ((m >> 4) * 2560 + row) * 16 + (m & 15) holds the value itself; the kernel splits it (hi = bf16(x), lo = bf16(x - hi)) per MFMA fragment.
+// Weight gradients bit-identical to ddnerf_mlp_x3_wgrad_packed on the split records of the same values; bias sums add the values.
+DDN_EXPORT int ddnerf_mlp_x3_wgrad_blocked(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
+                                           long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
+                                           int max_workgroups, ddnerf_stream_t stream) {
+    return wgrad_packed_impl<false, true>(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, ld, dst, dst_ld, dst_col0, dst_bias, workspace,
+                                          max_workgroups, stream);
+}
+DDN_EXPORT int ddnerf_mlp_x3_wgrad_blocked_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
+                                                float *dst, float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream) {
+    return wgrad_packed_skip_impl<false, true>(deltas, drow0, acts, arow_a, arow_b, M, ld, dst, dst_bias, workspace, max_workgroups, stream);
 }
 
 // The x3 training tier's weight gradients: the same jobs on records of bf16 ROW PAIRS (what ddnerf_mlp_x3_forward_train and

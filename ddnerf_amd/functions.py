@@ -90,10 +90,12 @@ class _MLPFunction(torch.autograd.Function):
             raw, acts, bits = ops.mlp_x3_forward_train(feat, _packed_weights(net), net.depth_head)
             ctx.save_for_backward(feat, acts, bits)
         else:
-            # with the default (bf16x3) weight gradients the exact-fp32 kernels record hi/lo words for the packed-operand kernel
-            # DDNERF_WGRAD: "x3" (default) hi/lo-word records, three MFMAs per product: fp32-class; "pairs": bf16 row-pair records,
-            # one MFMA per product (an opt-in speed mode: bf16-rounded operands); "f32": fp32 matrices and the fp32-MFMA kernel
-            ctx.rec = {"x3": "hilo", "pairs": "pairs"}.get(ops.WGRAD_MODE, False)
+            # with the default (bf16x3) weight gradients the exact-fp32 kernels write blocked RECORDS for the record-operand kernel
+            # DDNERF_WGRAD: "x3" (default) records of the fp32 values, split into hi/lo bf16 by the weight-gradient kernel, three MFMAs per
+            # product: fp32-class; "x3words": the same gradients from records of hi/lo words split by the recording kernels (round 4's
+            # form); "pairs": bf16 row-pair records, one MFMA per product (an opt-in speed mode: bf16-rounded operands); "f32": fp32
+            # matrices and the fp32-MFMA kernel
+            ctx.rec = {"x3": "values", "x3words": "hilo", "pairs": "pairs"}.get(ops.WGRAD_MODE, False)
             raw, acts = ops.mlp_f32_forward_train(feat, _packed_weights(net), net.depth_head, rec=ctx.rec)
             ctx.save_for_backward(feat, acts)
         net._fwd_calls = getattr(net, "_fwd_calls", 0) + 1
@@ -117,7 +119,7 @@ class _MLPFunction(torch.autograd.Function):
             deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head, rec=ctx.rec)
         # (the x3 tier's records of bf16 row pairs and the fp32 tier's records of hi/lo words go to the record-operand weight-gradient
         # kernel; DDNERF_WGRAD=f32 keeps fp32 matrices on the fp32 tier)
-        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3p" if (ctx.x3e or ctx.rec == "hilo") else ("x3h" if (ctx.x3 or ctx.rec == "pairs") else None))
+        flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3p" if (ctx.x3e or ctx.rec == "hilo") else ("x3h" if (ctx.x3 or ctx.rec == "pairs") else ("x3b" if ctx.rec == "values" else None)))
         net.last_flat_grad = flat_g  # the data-parallel bucket (ddnerf_amd.dist) reduces this buffer
         reducer = getattr(net, "grad_reducer", None)
         if reducer is not None:

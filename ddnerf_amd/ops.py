@@ -683,13 +683,14 @@ def mlp_f32_pack_t(params_flat, depth_head):
     return packed
 
 
-_REC_SUFFIX = {False: "", None: "", True: "_rec", "hilo": "_rec", "pairs": "_recp"}
+_REC_SUFFIX = {False: "", None: "", True: "_rec", "hilo": "_rec", "pairs": "_recp", "values": "_recf"}
 
 
 def mlp_f32_forward_train(feat, packed, depth_head, rec=False):
     """forward + recorded activations: returns raw [M,4|6], acts [2560, ld] (fp32, transposed: row = feature).  rec=True / "hilo": a
     record of blocked hi/lo words instead -- x3_unsplit reads it back -- for the packed-operand weight-gradient kernel; rec="pairs": a
-    record of bf16 row pairs ([1280, ld] words, x3_unpair reads it back) for the one-MFMA weight-gradient kernel"""
+    record of bf16 row pairs ([1280, ld] words, x3_unpair reads it back) for the one-MFMA weight-gradient kernel; rec="values": the blocked
+    layout of the hi/lo words holding the fp32 values themselves (x3_unblock reads it back), for ddnerf_mlp_x3_wgrad_blocked"""
     fn = "ddnerf_mlp_f32_forward_train" + _REC_SUFFIX[rec]
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
@@ -842,15 +843,19 @@ def ndc_depth_to_regular(ndc_depth, origins, directions):
 # weight-gradient arithmetic: "x3" = bf16 matrix cores with exact hi/lo operand splits (3 MFMAs per product, ~2^-16
 # relative product error, HBM-bound); "f32" = the fp32 matrix cores (exact fp32 products, MFMA-bound, 3x slower)
 # "x3p" = the same three-MFMA product on operands that already hold hi/lo words (what the x3 training kernels record)
-# DDNERF_WGRAD: "x3" (default) | "f32" | "pairs" (the fp32 tier's opt-in speed mode: its kernels record bf16 row pairs and the weight
-# gradients run the one-MFMA kernel "x3h").  Anything else is an error at import, not a KeyError in the first backward pass.
+# DDNERF_WGRAD (the fp32 tier's weight gradients): "x3" (default) = bf16 matrix cores on exact hi/lo splits, fp32-class; since round 5 the
+# recording kernels write blocked records of the fp32 VALUES and the weight-gradient kernel splits them per fragment ("x3b") | "x3words" = the
+# same gradients bit for bit from records of hi/lo WORDS split by the recording kernels (rounds 3-4; kept for the A/B: +0.3 ms per step)
+# | "f32" = fp32 matrices and the fp32-MFMA kernel | "pairs" (an opt-in speed mode: records of bf16 row pairs, one MFMA per product,
+# "x3h": NOT fp32-class).  Anything else is an error at import, not a KeyError in the first backward pass.
 WGRAD_MODE = os.environ.get("DDNERF_WGRAD", "x3")
-if WGRAD_MODE not in ("x3", "f32", "pairs"):
-    raise _lib.DDNerfHipError("DDNERF_WGRAD=%r: expected x3, f32 or pairs" % WGRAD_MODE)
+if WGRAD_MODE not in ("x3", "x3words", "f32", "pairs"):
+    raise _lib.DDNerfHipError("DDNERF_WGRAD=%r: expected x3, x3words, f32 or pairs" % WGRAD_MODE)
 # "x3h" = ONE MFMA per product on records of bf16 row pairs (the x3 training tier: its forward / backward-data chains stay fp32-class,
 # the weight gradients contract bf16-rounded activations and deltas with fp32 accumulation -- half the record bytes, a third of the MFMAs)
-_WGRAD_FN = {"x3": "ddnerf_mlp_x3_wgrad", "f32": "ddnerf_mlp_f32_wgrad", "x3p": "ddnerf_mlp_x3_wgrad_packed", "x3h": "ddnerf_mlp_x3_wgrad_pairs"}
-_RECORD_MODES = ("x3p", "x3h")
+_WGRAD_FN = {"x3": "ddnerf_mlp_x3_wgrad", "f32": "ddnerf_mlp_f32_wgrad", "x3p": "ddnerf_mlp_x3_wgrad_packed", "x3h": "ddnerf_mlp_x3_wgrad_pairs",
+             "x3b": "ddnerf_mlp_x3_wgrad_blocked"}
+_RECORD_MODES = ("x3p", "x3h", "x3b")
 
 
 WGRAD_PAIRED = os.environ.get("DDNERF_WGRAD_PAIRED", "1") != "0"
@@ -894,6 +899,19 @@ def x3_unpair(rec):
     return out
 
 
+def x3_block(x):
+    """fp32 [2560, ld] ([feature][sample]) -> the blocked record of the same VALUES (ddnerf_mlp_x3_wgrad_blocked's operands, what
+    mlp_f32_forward_train(rec="values") writes): element (row, m) at word ((m >> 4) * 2560 + row) * 16 + (m & 15)"""
+    assert x.shape[0] == ACT_ROWS and x.shape[1] % 16 == 0
+    return x.view(ACT_ROWS, x.shape[1] // 16, 16).permute(1, 0, 2).contiguous().view(ACT_ROWS, x.shape[1])
+
+
+def x3_unblock(rec):
+    """the inverse of x3_block"""
+    ld = rec.shape[1]
+    return rec.view(ld // 16, ACT_ROWS, 16).permute(1, 0, 2).reshape(ACT_ROWS, ld)
+
+
 def x3_unsplit(rec):
     """a record of the x3 training tier -> fp32 [2560, ld] values hi + lo (differs from the recorded value by <= 2^-17 relative)"""
     ld = rec.shape[1]
@@ -904,7 +922,7 @@ def x3_unsplit(rec):
 def mlp_f32_wgrad_job(deltas, drow0, n_out, acts, arow0, n_in, n_in_used, M, dst, dst_ld, dst_col0, dst_bias, workspace,
                       mode=None, max_wg=0):
     """dst[r*dst_ld + dst_col0 + c] = sum_s deltas[drow0+r][s] * acts[arow0+c][s]; dst_bias[r] = sum_s deltas[drow0+r][s]"""
-    mode = mode or {"pairs": "x3h"}.get(WGRAD_MODE, WGRAD_MODE)    # (a record-format name is not a kernel name)
+    mode = mode or {"pairs": "x3h", "x3words": "x3p"}.get(WGRAD_MODE, WGRAD_MODE)    # (a record-format name is not a kernel name)
     fn = getattr(_lib.lib(), _WGRAD_FN[mode])
     extra = (int(max_wg),) if mode in _RECORD_MODES else ()
     _lib.check(fn(_ptr(deltas), drow0, n_out, _ptr(acts), arow0, n_in, n_in_used, M, deltas.shape[1], _ptr(dst), dst_ld,

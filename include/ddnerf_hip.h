@@ -382,6 +382,14 @@ int ddnerf_mlp_f32_forward_train_recp(const float *feat, const float *packed, in
                                   long ld, ddnerf_stream_t stream);
 int ddnerf_mlp_f32_backward_data_recp(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
                                   float *deltas, long M, long ld, ddnerf_stream_t stream);
+/* ... and with blocked records of the fp32 VALUES themselves (round 5): the layout of the hi/lo-word records -- element (row, sample m) at
+ * word index ((m >> 4) * 2560 + row) * 16 + (m & 15) -- holding the value unsplit.  The weight gradients then run on
+ * ddnerf_mlp_x3_wgrad_blocked(_skip), which makes the same hi / lo split per MFMA fragment: the same weight gradients bit for bit as the
+ * hi/lo-word path, and these kernels' fp32 MFMA chains lose the 3.5 vector-ALU instructions per recorded element (each stops the chain). */
+int ddnerf_mlp_f32_forward_train_recf(const float *feat, const float *packed, int depth_head, float *raw, float *acts, long M,
+                                  long ld, ddnerf_stream_t stream);
+int ddnerf_mlp_f32_backward_data_recf(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
+                                  float *deltas, long M, long ld, ddnerf_stream_t stream);
 size_t ddnerf_mlp_f32_wgrad_workspace_floats(long M);
 int ddnerf_mlp_f32_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,
                          long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
@@ -419,6 +427,15 @@ int ddnerf_mlp_x3_wgrad_pairs(const void *deltas, int drow0, int n_out, const vo
 int ddnerf_mlp_x3_wgrad_pairs_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
                                    float *dst, float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream);
 int ddnerf_mlp_x3_split_pairs(const float *x, int rows, long ld, int row0, void *record, ddnerf_stream_t stream);
+/* The same jobs as ddnerf_mlp_x3_wgrad_packed(_skip) on blocked records of fp32 VALUES (what ddnerf_mlp_f32_forward_train_recf and
+ * ddnerf_mlp_f32_backward_data_recf write): the kernel splits every value into bf16 hi / lo (round to nearest even, lo = bf16(x - hi)) as it
+ * builds its MFMA fragments.  Weight gradients bit-identical to ddnerf_mlp_x3_wgrad_packed on the hi/lo-word records of the same values;
+ * bias sums add the values.  Pad columns as there. */
+int ddnerf_mlp_x3_wgrad_blocked(const void *deltas, int drow0, int n_out, const void *acts, int arow0, int n_in, int n_in_used,
+                                long M, long ld, float *dst, int dst_ld, int dst_col0, float *dst_bias, float *workspace,
+                                int max_workgroups, ddnerf_stream_t stream);
+int ddnerf_mlp_x3_wgrad_blocked_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,
+                                     float *dst, float *dst_bias, float *workspace, int max_workgroups, ddnerf_stream_t stream);
 /* layers_xyz.5 (input cat(xyz, h4)) as ONE job over the same records: dst [256][352] = rows drow0.. of `deltas` against
  * cat(acts rows arow_a .. +96, acts rows arow_b .. +256); dst_bias [256]. */
 int ddnerf_mlp_x3_wgrad_packed_skip(const void *deltas, int drow0, const void *acts, int arow_a, int arow_b, long M, long ld,

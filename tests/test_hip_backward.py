@@ -119,7 +119,7 @@ def test_dp_loss_backward_well_conditioned_vs_fp64_autograd(ops, blender):
         close(mine, 3.0 * r, 2e-3, 2e-5 * float(r.abs().max()) * 3.0)
 
 
-@pytest.mark.parametrize("mlp_dtype", ["fp32", "x3", "x3-exact", "fp32-pairs"])
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "fp32-words", "fp32-values", "x3", "x3-exact", "fp32-pairs"])
 @pytest.mark.parametrize("depth,M", [(True, 200), (False, 129), (True, 1000)])
 def test_mlp_backward_vs_autograd(ops, monkeypatch, depth, M, mlp_dtype):
     """forward_train + backward_data + weight gradients of one network against torch autograd on the fp32 restatement;
@@ -144,6 +144,11 @@ def test_mlp_backward_vs_autograd(ops, monkeypatch, depth, M, mlp_dtype):
     if pairs:
         mlp_dtype = "fp32"
         monkeypatch.setattr(ops, "WGRAD_MODE", "pairs")
+    # "fp32-words" / "fp32-values": the fp32 tier's two fp32-class record formats named explicitly (one of them is the default "fp32"):
+    # blocked fp32 values split by the weight-gradient kernel (DDNERF_WGRAD=x3), hi/lo words split by the recording kernels (=x3words)
+    if mlp_dtype in ("fp32-words", "fp32-values"):
+        monkeypatch.setattr(ops, "WGRAD_MODE", {"fp32-words": "x3words", "fp32-values": "x3"}[mlp_dtype])
+        mlp_dtype = "fp32"
 
     # every record / sign-word buffer the training kernels get is pre-filled with NaN patterns (all-ones words: a NaN as fp32, as a
     # hi/lo word and as a bf16 pair): pad columns (samples M .. ld) and rows nobody writes must not leak into a weight gradient
@@ -340,14 +345,16 @@ def test_weight_gradient_kernels_at_full_size(ops):
     rec_a, rec_d = ops.x3_split(acts), ops.x3_split(deltas)
     assert float((ops.x3_unsplit(rec_a) - acts).abs().max()) <= 2.0 ** -16 * float(acts.abs().max())
     pair_a, pair_d = ops.x3_split_pairs(acts), ops.x3_split_pairs(deltas)
+    blk_a, blk_d = ops.x3_block(acts), ops.x3_block(deltas)
+    assert torch.equal(ops.x3_unblock(blk_a)[::97], acts[::97])
     assert torch.equal(ops.x3_unpair(pair_a)[::97], acts[::97].bfloat16().float())
     for drow0, n_out, arow0, n_in, used, col0, ld in ((512, 256, 256, 256, 256, 0, 256), (0, 256, 2432, 96, 96, 0, 96),
                                                       (1280, 256, 1024, 256, 256, 96, 352), (2432, 3, 2304, 128, 128, 0, 128)):
         outs = {}
-        for mode in ("x3", "f32", "x3p"):
+        for mode in ("x3", "f32", "x3p", "x3b"):
             w = torch.zeros(n_out, ld, device="cuda")
             b = torch.zeros(n_out, device="cuda")
-            D, A = (rec_d, rec_a) if mode == "x3p" else (deltas, acts)
+            D, A = (rec_d, rec_a) if mode == "x3p" else ((blk_d, blk_a) if mode == "x3b" else (deltas, acts))
             ops.mlp_f32_wgrad_job(D, drow0, n_out, A, arow0, n_in, used, M, w, ld, col0, b, ws, mode=mode)
             outs[mode] = (w.clone(), b.clone())
         ref_w = deltas[drow0:drow0 + n_out] @ acts[arow0:arow0 + used].T
@@ -360,6 +367,7 @@ def test_weight_gradient_kernels_at_full_size(ops):
                 assert float(w[:, :col0].abs().max()) == 0.0          # columns outside the job are not touched
         assert float((outs["x3"][0] - outs["f32"][0]).abs().max()) <= 5e-5 * scale
         assert torch.equal(outs["x3"][0], outs["x3p"][0])   # same splits, same partition, same MFMA order: bit-identical
+        assert torch.equal(outs["x3"][0], outs["x3b"][0])   # (round 5) blocked records of the VALUES, split per fragment inside the kernel: the same
         # the x3 training tier's kernel: records of bf16 row pairs, one MFMA per product -- exact on the bf16-rounded operands,
         # and the usual mixed-precision distance (2^-9 per product, random signs) from the fp32 ones
         w = torch.zeros(n_out, ld, device="cuda")
@@ -384,6 +392,13 @@ def test_weight_gradient_kernels_at_full_size(ops):
                                                                   torch.cuda.current_stream().cuda_stream), "skip")
     assert torch.equal(w1, w2)
     assert float((b1 - b2).abs().max()) <= 1e-6 * float(b2.abs().max())
+    w4 = torch.zeros(256, 352, device="cuda")
+    b4 = torch.zeros(256, device="cuda")
+    ops._lib.check(ops._lib.lib().ddnerf_mlp_x3_wgrad_blocked_skip(blk_d.data_ptr(), 1280, blk_a.data_ptr(), 2432, 1024, M, blk_d.shape[1],
+                                                                   w4.data_ptr(), b4.data_ptr(), ws.data_ptr(), 0,
+                                                                   torch.cuda.current_stream().cuda_stream), "blocked_skip")
+    assert torch.equal(w4, w1)
+    assert float((b4 - b1).abs().max()) <= 1e-5 * float(b1.abs().max())
     w3 = torch.zeros(256, 352, device="cuda")
     b3 = torch.zeros(256, device="cuda")
     ops._lib.check(ops._lib.lib().ddnerf_mlp_x3_wgrad_pairs_skip(pair_d.data_ptr(), 1280, pair_a.data_ptr(), 2432, 1024, M, pair_d.shape[1],
@@ -425,6 +440,13 @@ def test_training_kernels_at_full_size(ops):
     d_r = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_r, depth, rec=True)
     assert torch.equal(d_r.view(torch.int32).reshape(-1, 2560, 16)[:, :2438], ops.x3_split(d_f).view(torch.int32).reshape(-1, 2560, 16)[:, :2438])
     del raw_r, acts_r, d_r
+    # (round 5) ... and the build that records the VALUES in that blocked layout, for the weight-gradient kernel that splits them itself
+    raw_v, acts_v = ops.mlp_f32_forward_train(feat, ops.mlp_f32_pack(flat, depth), depth, rec="values")
+    assert torch.equal(raw_v, raw_f)
+    assert torch.equal(acts_v.view(torch.int32)[:, :M].reshape(-1, 2560, 16)[:, :2555], ops.x3_block(acts_f).view(torch.int32)[:, :M].reshape(-1, 2560, 16)[:, :2555])
+    d_v = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_v, depth, rec="values")
+    assert torch.equal(d_v.view(torch.int32).reshape(-1, 2560, 16)[:, :2438], ops.x3_block(d_f).view(torch.int32).reshape(-1, 2560, 16)[:, :2438])
+    del raw_v, acts_v, d_v
     rows = torch.cat([torch.arange(0, 2432, 41, device="cuda"), torch.arange(2432, 2438, device="cuda")])
     a, b = d_f[rows], ops.x3_unpair(d_x)[rows]                                      # (bf16 roundings of the x3 chain's deltas)
     off = (a - b).abs() > 2.0 ** -7 * a.abs() + 1e-4 * float(a.abs().max())

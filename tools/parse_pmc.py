@@ -23,7 +23,7 @@ mfma = {}
 # + the [4096,32] fp32 table + the outputs.
 for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_rays_kernel<false>", 524288 * (384 + 16) + 4096 * 128), ("bf16", "void mlp_bf16g2e_fwd_kernel<false>", 4096 * 129 * 4 + 4096 * 128 + 524288 * 16),
                         ("bf16u", "void mlp_bf16g2_fwd_kernel<false>", 524288 * (256 + 16)),
-                        ("fp16", "void mlp_f16g2_fwd_kernel<false>", 524288 * (256 + 16)),
+                        ("fp16", "void mlp_f16g2e_fwd_kernel<false>", 4096 * 129 * 4 + 4096 * 128 + 524288 * 16),
                         ("x3", "void mlp_x3_fwd16_rays_kernel<false>", 524288 * (384 + 16) + 4096 * 128)):
     f = agg(os.path.join(P, "fetch_" + mlp, "c_counter_collection.csv"))
     w = agg(os.path.join(P, "write_" + mlp, "c_counter_collection.csv"))
@@ -37,11 +37,11 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_rays_kernel<false>", 524288 *
     # fp32 / x3: the guide's gfx950 rule (FETCH_SIZE doubled; calibrated 0.563 for their lane-per-row pattern, kept at the
     # conservative 2x).  bf16: the kernel reads 64-byte quarter rows, which the counter tallies differently: divide by the
     # factor measured on the same pattern in the same call.
-    fetch_true_kb = fk["FETCH_SIZE_raw_KB"] / BF16_FACTOR if mlp in ("bf16u", "fp16") else 2 * fk["FETCH_SIZE_raw_KB"]
+    fetch_true_kb = fk["FETCH_SIZE_raw_KB"] / BF16_FACTOR if mlp == "bf16u" else 2 * fk["FETCH_SIZE_raw_KB"]
     traffic = (fetch_true_kb + fk["WRITE_SIZE_KB"]) * 1024
     BF = ["mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_bf16_g2_body_d0.gen.inc", "mlp_bf16_g2e_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]
     srcs = {"fp32": ["mlp_f32.hip", "mlp_f32_fwd.inc", "mlp_f32_common.h"], "bf16": BF, "bf16u": BF, "x3": ["mlp_x3_fwd.hip", "mlp_x3_fwd_rays.hip", "mlp_mfma16.inc", "mlp_bf16_common.h"],
-            "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}[mlp]
+            "fp16": ["mlp_f16.hip", "mlp_f16_g2.hip", "mlp_f16_g2e.hip", "mlp_bf16.hip", "mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_f16_g2_body_d0.gen.inc", "mlp_f16_g2e_body_d0.gen.inc", "mlp_bf16_g2_tables.gen.inc", "mlp_mfma16.inc", "mlp_bf16_common.h"]}[mlp]
     digest = hashlib.md5()
     for f_ in srcs:
         digest.update(open(os.path.join(R, "ddnerf_amd", "csrc", f_), "rb").read())
@@ -55,17 +55,17 @@ for mlp, kern, algo in (("fp32", "void mlp_f32_fwd_rays_kernel<false>", 524288 *
                    "%.0f KB with the MLP kernels' access pattern (lane = sample, 16-B pieces of its own 512-B row: %.3f of the bytes)."
                    % (mlp, cal["calib_stream"], cal["calib_rows"], cal["calib_rows"] / TRUE_KB),
            "fetch_calibration": {"calib_stream_raw_over_true": round(cal["calib_stream"] / TRUE_KB, 4), "calib_rows_raw_over_true": round(cal["calib_rows"] / TRUE_KB, 4),
-                                 "calib_bf16rows_raw_over_true": round(BF16_FACTOR, 4), "applied": "raw / calib_bf16rows" if mlp in ("bf16u", "fp16") else "raw x 2"},
+                                 "calib_bf16rows_raw_over_true": round(BF16_FACTOR, 4), "applied": "raw / calib_bf16rows" if mlp == "bf16u" else "raw x 2"},
            "fine_mlp_%s_fwd_hbm_bytes_per_launch" % mlp: traffic, "algorithmic_bytes_per_launch": algo,
            "why_above_algorithmic": ("the fused kernel reads 2.6 MB of fenceposts and ray-table rows and writes 8.4 MB of outputs; its encoded rows live in a scratch area "
                                      "private to each workgroup (96 KiB x 256 workgroups = 25 MB, rewritten and re-read every tile): what the counters show above the "
                                      "algorithmic bytes is that scratch spilling from the 4-MB L2 of each XCD to the memory side (the MALL in front of HBM cannot be "
-                                     "told apart from HBM by FETCH_SIZE / WRITE_SIZE) plus the packed weight image (1.4 MB per XCD per pass)" if mlp == "bf16" else
+                                     "told apart from HBM by FETCH_SIZE / WRITE_SIZE) plus the packed weight image (1.4 MB per XCD per pass)" if mlp in ("bf16", "fp16") else
                                      "at this size the bf16 / fp16 forward is the two-group kernel (mlp_bf16_g2.hip): it does not keep the encoded row in registers "
                                      "(they hold a second group's activations instead) but fetches the 96 xyz columns again for the skip layer and the 32 "
                                      "view-direction columns again for the dir layer, one or two passes ahead of their use: re-reads of rows this workgroup "
                                      "fetched 50 us earlier, served by the L2 / MALL when they are still there and counted here when not; plus the packed weight "
-                                     "image (1.4 MB per XCD) and write granularity.  At the measured launch time the total is < 15 % of HBM bandwidth" if mlp in ("bf16u", "fp16") else
+                                     "image (1.4 MB per XCD) and write granularity.  At the measured launch time the total is < 15 % of HBM bandwidth" if mlp == "bf16u" else
                                      ("the fp32 kernel keeps its tile's xyz feature columns in LDS for the skip layer and reads the features non-temporally, its weight slices travel by LDS-DMA (round 4: 692 -> 320 MB); "
                                       "what is left above the algorithmic bytes is the weight image (2.4 MB) streaming through eight L2s once per 128-sample tile "
                                       "and the counter's conservative 2x correction; at the measured launch time < 2 % of HBM bandwidth" if mlp == "fp32" else
