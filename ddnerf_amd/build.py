@@ -64,6 +64,9 @@ CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_bf16_g2.hip": "mlp_bf16g2
 # kernels whose tile body is one block of assembly that owns the whole vector register file from its first iteration on: the loop
 # that the compiler wraps around it must be scalar code only
 ASM_BODY = {"mlp_bf16_g2.hip", "mlp_bf16_g2e.hip", "mlp_f16_g2.hip", "mlp_f16_g2e.hip"}
+# kernels that issue scalar loads from inline asm, unknown to the compiler's s_waitcnt insertion: no instruction may touch a load's
+# destination between the request and the hand-placed wait (check_asm_hazards.check_hidden_sloads); a violation fails the build
+SLOAD_CHECKED = {"mlp_f32_train_recf.hip": "mlp_f32_bwd_data_kernel_recf"}
 
 
 def _compile_checked(cmd, src, obj, kernel, verbose):
@@ -80,6 +83,15 @@ def _compile_checked(cmd, src, obj, kernel, verbose):
             print(" ".join(c), flush=True)
         subprocess.check_call(c)
         asm = os.path.join(tmp, base[:-2] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        if src in SLOAD_CHECKED:
+            n, bad = check_asm_hazards.check_hidden_sloads(asm, SLOAD_CHECKED[src])
+            if bad or not n:
+                raise RuntimeError("%s: %d scalar loads issued from inline asm; %d instructions touch a destination register before its "
+                                   "wait, e.g.\n%s" % (src, n, len(bad), bad[0] if bad else "(no such load found: the check is not looking at the kernel)"))
+            if verbose:
+                print("%s: %d scalar loads issued from inline asm, none of their destinations touched before its wait" % (src, n), flush=True)
+            shutil.move(os.path.join(tmp, base), obj)
+            return
         n, bad = check_asm_hazards.check(asm, kernel)
         if bad:
             raise RuntimeError("%s: %d dependent instruction pairs closer than the unpadded wait states, e.g.\n%s" % (src, len(bad), bad[0]))
@@ -154,8 +166,8 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
 
     def run(cmd):
         src = os.path.basename(cmd[-3])
-        if src in CHECKED and cmd[-2] == "-o":
-            return _compile_checked(cmd, src, cmd[-1], CHECKED[src], verbose)
+        if (src in CHECKED or src in SLOAD_CHECKED) and cmd[-2] == "-o":
+            return _compile_checked(cmd, src, cmd[-1], CHECKED.get(src), verbose)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -8,7 +8,8 @@ silently (it did once: outputs off by 1e-3).  This script scans the compiler's a
 when a dependent pair comes closer than the distances below (counted in wait states: one per instruction, n + 1 for
 `s_nop n`, 2 for an MFMA in between, which holds the issue port for 8 cycles).
 
-usage: check_asm_hazards.py file.s [kernel-name-substring]"""
+usage: check_asm_hazards.py file.s [kernel-name-substring]
+       check_asm_hazards.py file.s kernel-name-substring --sload      (check_hidden_sloads below)"""
 import re
 import sys
 
@@ -171,7 +172,66 @@ def check_scalar_shell(path, kernel):
     return bad
 
 
+SREG = re.compile(r"\bs(?:(\d+)|\[(\d+):(\d+)\])")
+
+
+def sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        lo = int(m.group(1) if m.group(1) is not None else m.group(2))
+        hi = int(m.group(1) if m.group(1) is not None else m.group(3))
+        out.update(range(lo, hi + 1))
+    return out
+
+
+def check_hidden_sloads(path, kernel):
+    """Scalar loads issued from inline asm (mlp_f32_train.hip, SignLoader: the compiler's s_waitcnt insertion does not know them) deliver
+    into registers the compiler believes are already written.  From such a load to the next `s_waitcnt ... lgkmcnt(0)` in program order
+    NO instruction may read or write its destination registers -- a register-allocator copy or spill placed there would move stale
+    bits.  Straight-line scan in text order (the kernel has no loop around these loads).  Returns (number of hidden loads, offending lines)."""
+    bad, on, inside, pending, n = [], False, False, {}, 0
+    for line in open(path):
+        if re.match(r"^_Z\w*%s\w*:" % kernel, line):
+            on, inside, pending = True, False, {}
+            continue
+        if not on:
+            continue
+        t = line.strip()
+        if ";#ASMSTART" in t:
+            inside = True
+            continue
+        if ";#ASMEND" in t:
+            inside = False
+            continue
+        if t.startswith("s_endpgm"):
+            if pending:
+                bad.append("s_endpgm with scalar loads never waited for: s%s" % sorted(pending))
+            on = False
+            continue
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        code = t.split(";")[0]
+        if code.startswith("s_waitcnt") and "lgkmcnt(0)" in code:
+            pending = {}
+            continue
+        touched = sregs(code.partition(" ")[2])
+        hit = touched & set(pending)
+        if hit:
+            bad.append("%s   <- touches s%s, requested by `%s` and not yet waited for" % (t, sorted(hit), pending[min(hit)]))
+        if inside and code.startswith("s_load_dword"):
+            n += 1
+            for r in sregs(code.partition(" ")[2].split(",")[0]):
+                pending[r] = code
+    return n, bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "--sload":
+        n, bad = check_hidden_sloads(sys.argv[1], sys.argv[2])
+        for b in bad[:20]:
+            print(b)
+        print("check_asm_hazards --sload: %d scalar loads issued from inline asm, %d instructions touch a destination before its wait" % (n, len(bad)))
+        sys.exit(1 if bad or not n else 0)
     n, bad = check(sys.argv[1], *(sys.argv[2:3]))
     for b in bad[:20]:
         print(b)

@@ -250,8 +250,43 @@ __device__ __forceinline__ bool tile_positive(float a) { return a > 0.0f; }
 // stores behind each slice's last MFMA, 1.2 vector-ALU instructions per MFMA) ran at 0.80 of the inference kernel's rate.
 #include "mlp_f32_fwd.inc"
 
+// ReLU masks (round 5, the values-record build): one bit per recorded activation of layers_xyz.0-7, laid out for the BACKWARD kernel's wave:
+// in the 32 x 32 accumulator layout a v_cmp on register r of a tile gives 64 bits -- bit 32 h + j = (row tile_row(r, h), sample j) > 0 --
+// in a scalar register pair, which is exactly the condition operand of the v_cndmask that masks register r of the delta tile of the same
+// rows and samples.  Sign record: [128-sample tile][32-row block rb = row / 32, 64 of them][wave, 4][register r, 16] 64-bit masks: 32 KiB
+// per tile, 1 bit per value (the backward read 32 bits per value only to take this bit: 4.8 GB per fine pass).  Written by scalar stores
+// (s_store_dwordx2: no vector-ALU instruction between the compare and memory; data read at issue, tools/calib/sstore.hip), read by scalar
+// loads.
+#define F32_SIGN_TILE_BYTES (64 * 4 * 16 * 8)
+#if defined(F32_REC) && F32_REC == 3 && !defined(F32_NO_SIGNS)   // (-DF32_NO_SIGNS: the A/B build of tools/train_kernels_ab.py -- same
+#define F32_SIGNS 1                                               // entry points, masks from the recorded activations as in the other builds)
+#else
+#define F32_SIGNS 0
+#endif
 struct Recorder {
     static constexpr bool kActive = true;
+#if F32_SIGNS
+    static constexpr bool kSigns = true;
+    const char *signs;        // the sign record
+    const char *sbase;        // ... of this tile and wave (uniform)
+    unsigned long sg[4];      // the four masks of a gap, until their stores
+    __device__ __forceinline__ void sign4(const f32x16 &t, int g) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("v_cmp_lt_f32 %0, 0, %1" : "=s"(sg[k]) : "v"(t[4 * g + k]));
+    }
+    __device__ __forceinline__ void sign_store(int rec_row, int g, int k0 = 0, int k1 = 4) {
+#ifdef F32_EXP_NOSSTORE   // (diagnostic builds, tools/train_kernels_ab.py: timing only)
+        return;
+#endif
+#pragma unroll
+        for (int k = k0; k < k1; ++k)
+            asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(sg[k]), "s"(sbase), "s"((unsigned)((rec_row / 32) * 512 + (4 * g + k) * 8)) : "memory");
+    }
+#else
+    static constexpr bool kSigns = false;
+    __device__ __forceinline__ void sign4(const f32x16 &, int) {}
+    __device__ __forceinline__ void sign_store(int, int, int = 0, int = 4) {}
+#endif
 #if defined(F32_REC) && (F32_REC == 1 || F32_REC == 3) && !defined(F32_EXP_NOQUADS)   // (F32_EXP_NOQUADS: diagnostic build with the 4-byte stores)
     static constexpr bool kQuads = true;   // hi/lo words: one word per value, four consecutive samples of a row = 16 contiguous bytes
     unsigned voff_t;                       // this lane's byte offset for a quad (mlp_f32_fwd.inc: the transposed read of the scratch)
@@ -274,6 +309,9 @@ struct Recorder {
         tile = blockIdx.x & 15;   // (2 tiles = 2.6 MB per XCD)
 #endif
         rs = __builtin_amdgcn_make_buffer_rsrc((void *)((unsigned *)acts + (size_t)tile * 8 * kBlockWords), 0, 8 * kBlockWords * 4, 0x00020000);
+#if F32_SIGNS
+        sbase = signs + (size_t)tile * F32_SIGN_TILE_BYTES + (size_t)__builtin_amdgcn_readfirstlane(wave) * 128;
+#endif
 #if F32_REC == 2
         voff = 4u * ((unsigned)(wave * 2 + (j >> 4)) * kBlockWords + 2u * h * 16u + (j & 15));
 #else
@@ -352,17 +390,34 @@ struct FwdOffsets {
     int bias_off[NLAYERS];
 };
 
+// (the values-record build takes one more buffer: the sign record, F32_SIGN_TILE_BYTES per 128-sample tile)
+#if defined(F32_REC) && F32_REC == 3
+DDN_EXPORT size_t ddnerf_mlp_f32_sign_bytes(long ld) { return ld > 0 ? (size_t)((ld + 127) / 128) * F32_SIGN_TILE_BYTES : 0; }
+#define F32_SIGNS_PARAM , void *__restrict__ signs
+#define F32_SIGNS_CPARAM , const void *__restrict__ signs
+#define F32_SIGNS_ARG , signs
+#else
+#define F32_SIGNS_PARAM
+#define F32_SIGNS_CPARAM
+#define F32_SIGNS_ARG
+#endif
 template <bool DEPTH>
 __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_fwd_train_kernel)(const float *__restrict__ feat,
                                                                    const float *__restrict__ packed, FwdOffsets fo,
                                                                    float *__restrict__ raw, float *__restrict__ acts,
-                                                                   long M, long ld) {
+                                                                   long M, long ld F32_SIGNS_PARAM) {
     __shared__ __attribute__((aligned(16))) float lds[F32_FWD_LDS_FLOATS];
     Recorder rec;
     rec.acts = acts;
     rec.ld = (size_t)ld;
+#if F32_SIGNS
+    rec.signs = (const char *)signs;
+#endif
     // (tiles past M inside ld -- ld is a multiple of 128 -- are recorded too, from the last sample's features: their deltas are zero)
     mlp_f32_forward_tiles<DEPTH>(lds, feat, packed, 4u * (unsigned)fo.bias_off[0], raw, M, rec);
+#if F32_SIGNS
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");   // the scalar stores leave the scalar data cache
+#endif
 }
 
 static FwdOffsets fwd_offsets() {
@@ -377,8 +432,11 @@ static FwdOffsets fwd_offsets() {
 }
 
 DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_forward_train)(const float *feat, const float *packed, int depth_head, float *raw,
-                                            float *acts, long M, long ld, ddnerf_stream_t stream) {
+                                            float *acts F32_SIGNS_PARAM, long M, long ld, ddnerf_stream_t stream) {
     DDN_REQUIRE(feat && packed && raw && acts, DDNERF_E_ARG);
+#if defined(F32_REC) && F32_REC == 3
+    DDN_REQUIRE(signs && ddn_aligned(signs, 128), DDNERF_E_ARG);
+#endif
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ld >= M && ld % 128 == 0, DDNERF_E_RANGE);
 #ifndef F32_REC
@@ -390,10 +448,10 @@ DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_forward_train)(const float *feat, const f
     dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));   // persistent (mlp_f32_fwd.inc)
     if (depth_head)
         hipLaunchKernelGGL(F32_NAME(mlp_f32_fwd_train_kernel)<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
-                           acts, M, ld);
+                           acts, M, ld F32_SIGNS_ARG);
     else
         hipLaunchKernelGGL(F32_NAME(mlp_f32_fwd_train_kernel)<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
-                           acts, M, ld);
+                           acts, M, ld F32_SIGNS_ARG);
     return ddn_launch_status();
 }
 
@@ -557,11 +615,98 @@ __device__ __forceinline__ void step_bwd_early(__amdgpu_buffer_rsrc_t wsrc, unsi
     act_first = act_hold;
 }
 
+#if F32_SIGNS
+// The values-record build (round 5): the ReLU masks of steps d2 .. d9 come from the forward's SIGN record (Recorder above) instead of from
+// the recorded activations -- per 32 x 32 tile two s_load_dwordx16 (one 64-bit mask per accumulator register, 128 contiguous bytes per
+// wave and tile) instead of sixteen 4-byte vector loads per lane (4.8 GB per fine pass, and every vector-memory instruction costs the fp32
+// MFMA chain ~12 cycles), and ONE v_cndmask per register on the scalar pair instead of a compare and a select.
+// The scalar loads are inline assembly the compiler's s_waitcnt insertion does not see (a compiler-issued scalar load would make the
+// NEXT wait for an LDS result an lgkmcnt(0) -- scalar loads return out of order -- and stall the MFMA chain for the load's full latency):
+//   * the masks of the tile a slice computes are requested behind that slice's record stores (chunks q0 + 4, q0 + 5), into the ONE
+//     set of 16 scalar pairs whose last use (the tile before's) was chunk q0 + 3;
+//   * `s_waitcnt lgkmcnt(0)` sits behind the last MFMA of chunk q0 - 1 of the NEXT slice (3 us later; nothing of the wave's own LDS
+//     traffic is in flight there), in front of their first use;
+//   * a hidden outstanding scalar load only makes the compiler's own lgkmcnt(N) waits conservative (one more LDS operation has to be
+//     back than it asked for), never wrong;
+//   * between a request and that wait NO instruction may touch the pairs (a register-allocator copy would read them early):
+//     csrc/check_asm_hazards.py --sload scans the kernel's assembly for exactly that and fails the build.
+typedef unsigned u32x16s __attribute__((ext_vector_type(16)));
+struct SignMasks {   // the sixteen 64-bit lane masks of one tile: registers 0..7 in `a`, 8..15 in `b` (two 16-register scalar tuples)
+    u32x16s a, b;
+    // the data-dependent form of the wait: everything that reads the masks afterwards depends on THIS statement's results, so the
+    // compiler cannot move a use (or the scalar arithmetic of one) in front of it
+    __device__ __forceinline__ void arrived() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory"); }
+    __device__ __forceinline__ unsigned long of(int r) const {
+        const u32x16s &v = r < 8 ? a : b;
+        return (unsigned long)v[2 * (r & 7)] | ((unsigned long)v[2 * (r & 7) + 1] << 32);
+    }
+};
+struct SignLoader {
+    const char *sbase;
+    __device__ __forceinline__ void begin_tile(const void *signs, long tile, int wave) {
+        sbase = (const char *)signs + (size_t)tile * F32_SIGN_TILE_BYTES + (size_t)__builtin_amdgcn_readfirstlane(wave) * 128;
+    }
+    // TWO loads per tile, not sixteen: every outstanding scalar load the compiler does not know of makes each of its lgkmcnt(N) waits for
+    // an LDS result wait for one operation more than it meant to -- with sixteen in flight (N <= 15) every such wait lasted until
+    // the scalar loads were back, 1 - 2 us per tile: the kernel ran 6 % SLOWER than with the fp32 activation loads
+    __device__ __forceinline__ void load_half(SignMasks &sm, int row0, int half) const {
+        const unsigned off = (unsigned)((row0 / 32) * 512 + half * 64);
+        if (half == 0) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(sm.a) : "s"(sbase), "s"(off) : "memory");
+        else asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(sm.b) : "s"(sbase), "s"(off) : "memory");
+    }
+};
+__device__ __forceinline__ float sign_mask(float x, unsigned long m) {
+    asm volatile("v_cndmask_b32 %0, 0, %0, %1" : "+v"(x) : "s"(m));
+    return x;
+}
+
+template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK, int PEND>
+__device__ __forceinline__ void step_bwd_signs(__amdgpu_buffer_rsrc_t wsrc, unsigned &woff, float *lds, float *scr_wave, f32x16 (&Breg)[12],
+                                               f32x16 (&out)[8], f32x4 (&carry)[2], SignMasks &sm, const SignLoader &sl,
+                                               Recorder &rec, int row0, int pend_row0, int tid, int lane) {
+    static_assert(!PEND || bsel<KIND>(9) != 7, "PEND: tile 7 must not feed the first ten chunks");
+    static_assert(K / 8 >= 20, "the round-trip schedule uses chunks 1 .. q0 + 7");
+    constexpr int ROUNDS = slice_floats(K) / 1024, NEXT_ROUNDS = NEXT_K > 0 ? slice_floats(NEXT_K) / 1024 : 0, NQ = K / 8;
+    float *scr = scr_wave + lane;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float *cur = lds + ((PAR + b) & 1) * MAX_SLICE_FLOATS;
+        float *nxt = lds + ((PAR + b + 1) & 1) * MAX_SLICE_FLOATS;
+        woff += 4096u * ROUNDS;
+        f32x16 bunused;
+        auto init = [&](f32x16 &a) { a = f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; };
+        auto mid = [&](int q, int i) {
+            const int R = b + 1 < NB ? ROUNDS : NEXT_ROUNDS;
+            const int after = R > 0 ? ((R - 1) * NQ) / (2 * R) + 1 : 7, q0 = after > 7 ? after : 7;
+            static_assert(NQ >= 20, "");
+            // the masks of the tile THIS slice computes (rows row0 + 32 b ..): used behind the next slice, or the next step's slice 0
+            if (MASK && i == 1 && q >= q0 + 4 && q < q0 + 6) sl.load_half(sm, row0 + 32 * b, q - q0 - 4);
+            const bool mine = b >= 1, pend = PEND != 0 && b == 0;
+            if (!mine && !pend) return;
+            f32x16 &t = mine ? out[b >= 1 ? b - 1 : 0] : Breg[7];
+            const bool masked = mine ? MASK : PEND == 1;
+            if (q >= 1 && q <= 4) plain_push(scr, t[4 * (q - 1) + i], 4 * (q - 1) + i);
+            if (q >= 5 && q <= 8) t[4 * (q - 5) + i] = relu_pull(scr, 4 * (q - 5) + i);
+            if (masked && q == q0 - 1 && i == 3) sm.arrived();   // the masks requested a slice ago
+            if (i == 0 && q >= q0 && q < q0 + 4) {   // mask (one select per element) and record four elements in one gap
+                if (masked) {
+#pragma unroll
+                    for (int r = 4 * (q - q0); r < 4 * (q - q0) + 4; ++r) t[r] = sign_mask(t[r], sm.of(r));
+                }
+                rec.store4(mine ? row0 + 32 * (b - 1) : pend_row0, t, q - q0);
+            }
+        };
+        if (b + 1 < NB) slice_step_early<KIND, K, ROUNDS, K, false>(wsrc, nullptr, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
+        else slice_step_early<KIND, K, NEXT_ROUNDS, NEXT_K, false>(wsrc, nullptr, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
+    }
+}
+#endif
+
 template <bool DEPTH>
 __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_bwd_data_kernel)(const float *__restrict__ g_raw,
                                                                   const float *__restrict__ packed_t, unsigned packed_bytes,
                                                                   const float *__restrict__ acts,
-                                                                  float *__restrict__ deltas, long M, long ld) {
+                                                                  float *__restrict__ deltas, long M, long ld F32_SIGNS_CPARAM) {
     __shared__ __attribute__((aligned(16))) float lds[F32_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -608,16 +753,50 @@ __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_bwd_data_kernel)(cons
     f32x4 carry[2];
     carry[0] = *(const f32x4 *)(lds + j * (160 + 4) + 4 * h);
     carry[1] = *(const f32x4 *)(lds + j * (160 + 4) + 4 * h + 8);
+    Recorder rec;
+    rec.acts = deltas;
+    rec.ld = (size_t)ld;
+#define NEXT_STEP() _Pragma("unroll") for (int b = 0; b < 8; ++b) Breg[b] = out[b];
+#if F32_SIGNS
+    rec.signs = nullptr;   // (the backward writes no sign record)
+    rec.begin_tile(blockIdx.x, wave, j, h);
+    SignLoader sl;
+    sl.begin_tile(signs, blockIdx.x, wave);
+    SignMasks sm;
+    sm.a = sm.b = u32x16s{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    step_bwd_signs<11, 160, 8, 256, 0, false, 0>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, ROW_FEAT, 0, tid, lane);
+    NEXT_STEP();
+    step_bwd_signs<1, 256, 8, 256, 0, true, 2>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 7, ROW_FEAT + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 6, 256 * 7 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 5, 256 * 6 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 4, 256 * 5 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 3, 256 * 4 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 2, 256 * 3 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 1, 256 * 2 + 224, tid, lane);
+    NEXT_STEP();
+    step_bwd_signs<1, 256, 8, 0, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 0, 256 * 1 + 224, tid, lane);
+#undef NEXT_STEP
+    {   // the last tile of the last step: nothing left to hide it behind
+        f32x16 a = out[7];
+        sm.arrived();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = sign_mask(a[r], sm.of(r));
+        rec.store(224, a);
+    }
+    return;
+#else
     ActLoader al;
     al.acts = acts;
     al.ld = (size_t)ld;
     al.begin_tile(blockIdx.x, wave, j, h);
-    Recorder rec;
-    rec.acts = deltas;
-    rec.ld = (size_t)ld;
     rec.begin_tile(blockIdx.x, wave, j, h);
     f32x16 act_pend = {}, act_first = {};
-#define NEXT_STEP() _Pragma("unroll") for (int b = 0; b < 8; ++b) Breg[b] = out[b];
     // d1: d(feat) = W_dir[:, :256]^T d(dir hidden) + W_alpha^T d(raw)[3]; fc_feat has no activation
     step_bwd_early<11, 160, 8, 256, 0, false, 0, true>(wsrc, woff, lds, scr_wave, Breg, out, carry, act_pend, act_first, al, rec, ROW_FEAT, 0, 256 * 7, tid, lane);
     NEXT_STEP();
@@ -645,11 +824,15 @@ __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_bwd_data_kernel)(cons
         for (int r = 0; r < 16; ++r) a[r] = tile_positive(act_pend[r]) ? a[r] : 0.0f;
         rec.store(224, a);
     }
+#endif
 }
 
-DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_backward_data)(const float *g_raw, const float *packed_t, const float *acts,
+DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_backward_data)(const float *g_raw, const float *packed_t, const float *acts F32_SIGNS_CPARAM,
                                             int depth_head, float *deltas, long M, long ld, ddnerf_stream_t stream) {
     DDN_REQUIRE(g_raw && packed_t && acts && deltas, DDNERF_E_ARG);
+#if defined(F32_REC) && F32_REC == 3
+    DDN_REQUIRE(signs && ddn_aligned(signs, 128), DDNERF_E_ARG);
+#endif
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ld >= M && ld % 128 == 0, DDNERF_E_RANGE);
 #ifndef F32_REC
@@ -660,9 +843,9 @@ DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_backward_data)(const float *g_raw, const 
     dim3 grid((unsigned)((M + 127) / 128));
     if (depth_head)
         hipLaunchKernelGGL(F32_NAME(mlp_f32_bwd_data_kernel)<true>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, packed_bytes, acts,
-                           deltas, M, ld);
+                           deltas, M, ld F32_SIGNS_ARG);
     else
         hipLaunchKernelGGL(F32_NAME(mlp_f32_bwd_data_kernel)<false>, grid, dim3(256), 0, (hipStream_t)stream, g_raw, packed_t, packed_bytes, acts,
-                           deltas, M, ld);
+                           deltas, M, ld F32_SIGNS_ARG);
     return ddn_launch_status();
 }

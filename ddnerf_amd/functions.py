@@ -96,8 +96,12 @@ class _MLPFunction(torch.autograd.Function):
             # form); "pairs": bf16 row-pair records, one MFMA per product (an opt-in speed mode: bf16-rounded operands); "f32": fp32
             # matrices and the fp32-MFMA kernel
             ctx.rec = {"x3": "values", "x3words": "hilo", "pairs": "pairs"}.get(ops.WGRAD_MODE, False)
-            raw, acts = ops.mlp_f32_forward_train(feat, _packed_weights(net), net.depth_head, rec=ctx.rec)
-            ctx.save_for_backward(feat, acts)
+            if ctx.rec == "values":
+                raw, acts, signs = ops.mlp_f32_forward_train(feat, _packed_weights(net), net.depth_head, rec=ctx.rec)
+                ctx.save_for_backward(feat, acts, signs)
+            else:
+                raw, acts = ops.mlp_f32_forward_train(feat, _packed_weights(net), net.depth_head, rec=ctx.rec)
+                ctx.save_for_backward(feat, acts)
         net._fwd_calls = getattr(net, "_fwd_calls", 0) + 1
         ctx.net = net
         return raw
@@ -114,9 +118,9 @@ class _MLPFunction(torch.autograd.Function):
             packed_t = _cached_pack(net, "x3_t", ops.mlp_x3_pack_t)
             deltas = ops.mlp_x3_backward_data(g_raw, packed_t, bits, net.depth_head)
         else:
-            feat, acts = ctx.saved_tensors
+            feat, acts, *signs = ctx.saved_tensors
             packed_t = _cached_pack(net, "fp32_t", ops.mlp_f32_pack_t)
-            deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head, rec=ctx.rec)
+            deltas = ops.mlp_f32_backward_data(g_raw, packed_t, acts, net.depth_head, rec=ctx.rec, signs=signs[0] if signs else None)
         # (the x3 tier's records of bf16 row pairs and the fp32 tier's records of hi/lo words go to the record-operand weight-gradient
         # kernel; DDNERF_WGRAD=f32 keeps fp32 matrices on the fp32 tier)
         flat_g, views = ops.mlp_f32_weight_grads(net, acts, deltas, g_raw.shape[0], mode="x3p" if (ctx.x3e or ctx.rec == "hilo") else ("x3h" if (ctx.x3 or ctx.rec == "pairs") else ("x3b" if ctx.rec == "values" else None)))

@@ -690,32 +690,41 @@ def mlp_f32_forward_train(feat, packed, depth_head, rec=False):
     """forward + recorded activations: returns raw [M,4|6], acts [2560, ld] (fp32, transposed: row = feature).  rec=True / "hilo": a
     record of blocked hi/lo words instead -- x3_unsplit reads it back -- for the packed-operand weight-gradient kernel; rec="pairs": a
     record of bf16 row pairs ([1280, ld] words, x3_unpair reads it back) for the one-MFMA weight-gradient kernel; rec="values": the blocked
-    layout of the hi/lo words holding the fp32 values themselves (x3_unblock reads it back), for ddnerf_mlp_x3_wgrad_blocked"""
+    layout of the hi/lo words holding the fp32 values themselves (x3_unblock reads it back), for ddnerf_mlp_x3_wgrad_blocked -- and a THIRD
+    result, the sign record (uint8 [ddnerf_mlp_f32_sign_bytes(ld)]) mlp_f32_backward_data(rec="values") takes its ReLU masks from"""
     fn = "ddnerf_mlp_f32_forward_train" + _REC_SUFFIX[rec]
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
     ld = (M + 127) // 128 * 128
     raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
     acts = _record((ACT_ROWS // 2 if rec == "pairs" else ACT_ROWS, ld), torch.float32, feat.device)
+    signs = _record((_lib.lib().ddnerf_mlp_f32_sign_bytes(ld),), torch.uint8, feat.device) if rec == "values" else None
+    extra = (_ptr(signs),) if rec == "values" else ()
 
     def launch():
-        _lib.check(getattr(_lib.lib(), fn)(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts), M, ld, _stream()), fn)
+        _lib.check(getattr(_lib.lib(), fn)(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts), *extra, M, ld, _stream()), fn)
 
     if MLP_LAUNCH_HOOK is not None:
         MLP_LAUNCH_HOOK(M, launch)
     else:
         launch()
-    return raw, acts
+    return (raw, acts, signs) if rec == "values" else (raw, acts)
 
 
-def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head, rec=False):
-    """rec: `acts` is a record (mlp_f32_forward_train(rec=...)) and so is the result, in the same format"""
+def mlp_f32_backward_data(g_raw, packed_t, acts, depth_head, rec=False, signs=None):
+    """rec: `acts` is a record (mlp_f32_forward_train(rec=...)) and so is the result, in the same format; rec="values" also takes the
+    forward's sign record"""
     fn = "ddnerf_mlp_f32_backward_data" + _REC_SUFFIX[rec]
     g_raw = _f32c(g_raw, "g_raw")
     M = g_raw.shape[0]
     ld = acts.shape[1]
     deltas = _record(tuple(acts.shape), acts.dtype, acts.device)
-    _lib.check(getattr(_lib.lib(), fn)(_ptr(g_raw), _ptr(packed_t), _ptr(acts), int(depth_head), _ptr(deltas), M, ld, _stream()), fn)
+    extra = ()
+    if rec == "values":
+        if signs is None or signs.dtype != torch.uint8 or signs.numel() != _lib.lib().ddnerf_mlp_f32_sign_bytes(ld) or signs.device != acts.device:
+            raise _lib.DDNerfHipError("mlp_f32_backward_data(rec='values'): signs must be the sign record mlp_f32_forward_train returned")
+        extra = (_ptr(signs),)
+    _lib.check(getattr(_lib.lib(), fn)(_ptr(g_raw), _ptr(packed_t), _ptr(acts), *extra, int(depth_head), _ptr(deltas), M, ld, _stream()), fn)
     return deltas
 
 

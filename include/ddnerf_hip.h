@@ -384,11 +384,16 @@ int ddnerf_mlp_f32_backward_data_recp(const float *g_raw, const float *packed_t,
                                   float *deltas, long M, long ld, ddnerf_stream_t stream);
 /* ... and with blocked records of the fp32 VALUES themselves (round 5): the layout of the hi/lo-word records -- element (row, sample m) at
  * word index ((m >> 4) * 2560 + row) * 16 + (m & 15) -- holding the value unsplit.  The weight gradients then run on
- * ddnerf_mlp_x3_wgrad_blocked(_skip), which makes the same hi / lo split per MFMA fragment: the same weight gradients bit for bit as the
- * hi/lo-word path, and these kernels' fp32 MFMA chains lose the 3.5 vector-ALU instructions per recorded element (each stops the chain). */
-int ddnerf_mlp_f32_forward_train_recf(const float *feat, const float *packed, int depth_head, float *raw, float *acts, long M,
-                                  long ld, ddnerf_stream_t stream);
-int ddnerf_mlp_f32_backward_data_recf(const float *g_raw, const float *packed_t, const float *acts, int depth_head,
+ * ddnerf_mlp_x3_wgrad_blocked(_skip), which makes the same hi / lo split once per landed slot: the same weight gradients bit for bit as the
+ * hi/lo-word path, and these kernels' fp32 MFMA chains lose the 3.5 vector-ALU instructions per recorded element (each stops the chain).
+ * `signs`: the SIGN record the forward also writes and the backward reads for its ReLU masks instead of the activations themselves (1 bit
+ * instead of 32 per value): ddnerf_mlp_f32_sign_bytes(ld) bytes, 128-byte aligned; per 128-sample tile 32 KiB = [32-row block of
+ * layers_xyz.0-7's outputs, 64][wave = 32 samples, 4][accumulator register r, 16] 64-bit lane masks (bit 32 h + j: row 32 block +
+ * (r & 3) + 8 (r >> 2) + 4 h, sample 32 wave + j, is > 0), written by scalar stores and read by scalar loads. */
+size_t ddnerf_mlp_f32_sign_bytes(long ld);
+int ddnerf_mlp_f32_forward_train_recf(const float *feat, const float *packed, int depth_head, float *raw, float *acts, void *signs,
+                                  long M, long ld, ddnerf_stream_t stream);
+int ddnerf_mlp_f32_backward_data_recf(const float *g_raw, const float *packed_t, const float *acts, const void *signs, int depth_head,
                                   float *deltas, long M, long ld, ddnerf_stream_t stream);
 size_t ddnerf_mlp_f32_wgrad_workspace_floats(long M);
 int ddnerf_mlp_f32_wgrad(const float *deltas, int drow0, int n_out, const float *acts, int arow0, int n_in, int n_in_used,

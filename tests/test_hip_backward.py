@@ -441,12 +441,23 @@ def test_training_kernels_at_full_size(ops):
     assert torch.equal(d_r.view(torch.int32).reshape(-1, 2560, 16)[:, :2438], ops.x3_split(d_f).view(torch.int32).reshape(-1, 2560, 16)[:, :2438])
     del raw_r, acts_r, d_r
     # (round 5) ... and the build that records the VALUES in that blocked layout, for the weight-gradient kernel that splits them itself
-    raw_v, acts_v = ops.mlp_f32_forward_train(feat, ops.mlp_f32_pack(flat, depth), depth, rec="values")
+    raw_v, acts_v, signs = ops.mlp_f32_forward_train(feat, ops.mlp_f32_pack(flat, depth), depth, rec="values")
     assert torch.equal(raw_v, raw_f)
     assert torch.equal(acts_v.view(torch.int32)[:, :M].reshape(-1, 2560, 16)[:, :2555], ops.x3_block(acts_f).view(torch.int32)[:, :M].reshape(-1, 2560, 16)[:, :2555])
-    d_v = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_v, depth, rec="values")
+    # ... with the sign record the backward takes its ReLU masks from: [128-sample tile][32-row block of layers_xyz.0-7][wave][register r] 64-bit
+    # lane masks, bit 32 h + j = (row 32 block + (r & 3) + 8 (r >> 2) + 4 h, sample 128 tile + 32 wave + j) > 0   (include/ddnerf_hip.h)
+    got = signs.view(torch.int64).view(M // 128, 64, 4, 16)
+    pos = (acts_f[:2048].view(64, 32, M // 128, 4, 32) > 0).permute(2, 0, 3, 1, 4)           # [tile, block, wave, row in block, j]
+    r = torch.arange(16, device="cuda")
+    shifts = torch.arange(32, device="cuda", dtype=torch.int64)
+    want = torch.zeros_like(got)
+    for h in range(2):
+        rows = (r & 3) + 8 * (r >> 2) + 4 * h                                                  # [16]
+        want |= (pos[:, :, :, rows, :].to(torch.int64) << (shifts + 32 * h)).sum(-1)           # (disjoint bits: the sum is their OR)
+    assert torch.equal(got, want)
+    d_v = ops.mlp_f32_backward_data(G, ops.mlp_f32_pack_t(flat, depth), acts_v, depth, rec="values", signs=signs)
     assert torch.equal(d_v.view(torch.int32).reshape(-1, 2560, 16)[:, :2438], ops.x3_block(d_f).view(torch.int32).reshape(-1, 2560, 16)[:, :2438])
-    del raw_v, acts_v, d_v
+    del raw_v, acts_v, d_v, signs, got, want, pos
     rows = torch.cat([torch.arange(0, 2432, 41, device="cuda"), torch.arange(2432, 2438, device="cuda")])
     a, b = d_f[rows], ops.x3_unpair(d_x)[rows]                                      # (bf16 roundings of the x3 chain's deltas)
     off = (a - b).abs() > 2.0 ** -7 * a.abs() + 1e-4 * float(a.abs().max())
