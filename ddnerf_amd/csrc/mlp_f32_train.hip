@@ -274,18 +274,20 @@ struct Recorder {
 #pragma unroll
         for (int k = 0; k < 4; ++k) asm volatile("v_cmp_lt_f32 %0, 0, %1" : "=s"(sg[k]) : "v"(t[4 * g + k]));
     }
-    __device__ __forceinline__ void sign_store(int rec_row, int g, int k0 = 0, int k1 = 4) {
+    __device__ __forceinline__ void sign_store(int rec_row, int g) {
 #ifdef F32_EXP_NOSSTORE   // (diagnostic builds, tools/train_kernels_ab.py: timing only)
         return;
 #endif
+        // (the scheduler otherwise hoists the stores over the MFMA in front of them, right behind the compares that wrote their data)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = k0; k < k1; ++k)
+        for (int k = 0; k < 4; ++k)
             asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(sg[k]), "s"(sbase), "s"((unsigned)((rec_row / 32) * 512 + (4 * g + k) * 8)) : "memory");
     }
 #else
     static constexpr bool kSigns = false;
     __device__ __forceinline__ void sign4(const f32x16 &, int) {}
-    __device__ __forceinline__ void sign_store(int, int, int = 0, int = 4) {}
+    __device__ __forceinline__ void sign_store(int, int) {}
 #endif
 #if defined(F32_REC) && (F32_REC == 1 || F32_REC == 3) && !defined(F32_EXP_NOQUADS)   // (F32_EXP_NOQUADS: diagnostic build with the 4-byte stores)
     static constexpr bool kQuads = true;   // hi/lo words: one word per value, four consecutive samples of a row = 16 contiguous bytes
