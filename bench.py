@@ -929,7 +929,14 @@ def train_roofline(args, cfg, step_s):
     else:
         ideal = (fwd + bwd) / (PEAK["fp32"] * 1e12) + wgrad / (PEAK["x3"] * 1e12)
         issued = (fwd + bwd) / (PEAK["fp32"] * 1e12) + 3 * wgrad / (PEAK["x3"] * 1e12)
+    from ddnerf_amd import ops as _o
+
+    records = ("bf16 row pairs and 16-bit sign words (the x3 tier's own kernels)" if args.mlp == "x3" else
+               {"x3": "blocked records of the fp32 values, split into bf16 hi / lo by the weight-gradient kernel; 1-bit ReLU masks through scalar memory (round 5)",
+                "x3words": "blocked records of hi/lo words split by the recording kernels (round 4's form)",
+                "pairs": "bf16 row pairs (opt-in speed mode, not fp32-class)", "f32": "fp32 [feature][sample] matrices"}[_o.WGRAD_MODE])
     return {"bound": "mfma", "kernel": "whole training step (forward + backward-data + weight gradients of both networks)",
+            "records": records, "wgrad_mode": _o.WGRAD_MODE if args.mlp == "fp32" else None,
             "algorithmic_flop_per_step": fwd + bwd + wgrad, "ideal_ms": round(ideal * 1e3, 4), "step_ms": round(step_s * 1e3, 4),
             "frac": round(ideal / step_s, 4), "frac_issued": round(issued / step_s, 4), "issued_ideal_ms": round(issued * 1e3, 4),
             "unit": "fraction of the step time the (algorithmic / issued) FLOP need at the dense MFMA peaks",

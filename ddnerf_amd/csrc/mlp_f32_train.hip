@@ -265,6 +265,11 @@ __device__ __forceinline__ bool tile_positive(float a) { return a > 0.0f; }
 #endif
 struct Recorder {
     static constexpr bool kActive = true;
+#ifdef F32_TRAIN_DMA   // (the weight slices by LDS-DMA, as in the inference kernel; the record stores stay outstanding across the slice's vmcnt wait)
+    static constexpr bool kDma = true;
+#else
+    static constexpr bool kDma = false;
+#endif
 #if F32_SIGNS
     static constexpr bool kSigns = true;
     const char *signs;        // the sign record
@@ -663,7 +668,7 @@ __device__ __forceinline__ float sign_mask(float x, unsigned long m) {
 }
 
 template <int KIND, int K, int NB, int NEXT_K, int PAR, bool MASK, int PEND>
-__device__ __forceinline__ void step_bwd_signs(__amdgpu_buffer_rsrc_t wsrc, unsigned &woff, float *lds, float *scr_wave, f32x16 (&Breg)[12],
+__device__ __forceinline__ void step_bwd_signs(__amdgpu_buffer_rsrc_t wsrc, const char *wptr, unsigned &woff, float *lds, float *scr_wave, f32x16 (&Breg)[12],
                                                f32x16 (&out)[8], f32x4 (&carry)[2], SignMasks &sm, const SignLoader &sl,
                                                Recorder &rec, int row0, int pend_row0, int tid, int lane) {
     static_assert(!PEND || bsel<KIND>(9) != 7, "PEND: tile 7 must not feed the first ten chunks");
@@ -698,8 +703,9 @@ __device__ __forceinline__ void step_bwd_signs(__amdgpu_buffer_rsrc_t wsrc, unsi
                 rec.store4(mine ? row0 + 32 * (b - 1) : pend_row0, t, q - q0);
             }
         };
-        if (b + 1 < NB) slice_step_early<KIND, K, ROUNDS, K, false>(wsrc, nullptr, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
-        else slice_step_early<KIND, K, NEXT_ROUNDS, NEXT_K, false>(wsrc, nullptr, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid);
+        const int vm_after = (b >= 1 || PEND != 0) ? 16 : 0;   // (this slice's record stores, behind its last piece)
+        if (b + 1 < NB) slice_step_early<KIND, K, ROUNDS, K, Recorder::kDma>(wsrc, wptr, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid, vm_after);
+        else slice_step_early<KIND, K, NEXT_ROUNDS, NEXT_K, Recorder::kDma>(wsrc, wptr, woff, cur, nxt, Breg, out[b], carry, bunused, tid, lane, init, mid, vm_after);
     }
 }
 #endif
@@ -766,23 +772,23 @@ __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_bwd_data_kernel)(cons
     sl.begin_tile(signs, blockIdx.x, wave);
     SignMasks sm;
     sm.a = sm.b = u32x16s{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    step_bwd_signs<11, 160, 8, 256, 0, false, 0>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, ROW_FEAT, 0, tid, lane);
+    step_bwd_signs<11, 160, 8, 256, 0, false, 0>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, ROW_FEAT, 0, tid, lane);
     NEXT_STEP();
-    step_bwd_signs<1, 256, 8, 256, 0, true, 2>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 7, ROW_FEAT + 224, tid, lane);
+    step_bwd_signs<1, 256, 8, 256, 0, true, 2>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 7, ROW_FEAT + 224, tid, lane);
     NEXT_STEP();
-    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 6, 256 * 7 + 224, tid, lane);
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 6, 256 * 7 + 224, tid, lane);
     NEXT_STEP();
-    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 5, 256 * 6 + 224, tid, lane);
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 5, 256 * 6 + 224, tid, lane);
     NEXT_STEP();
-    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 4, 256 * 5 + 224, tid, lane);
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 4, 256 * 5 + 224, tid, lane);
     NEXT_STEP();
-    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 3, 256 * 4 + 224, tid, lane);
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 3, 256 * 4 + 224, tid, lane);
     NEXT_STEP();
-    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 2, 256 * 3 + 224, tid, lane);
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 2, 256 * 3 + 224, tid, lane);
     NEXT_STEP();
-    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 1, 256 * 2 + 224, tid, lane);
+    step_bwd_signs<1, 256, 8, 256, 0, true, 1>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 256 * 1, 256 * 2 + 224, tid, lane);
     NEXT_STEP();
-    step_bwd_signs<1, 256, 8, 0, 0, true, 1>(wsrc, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 0, 256 * 1 + 224, tid, lane);
+    step_bwd_signs<1, 256, 8, 0, 0, true, 1>(wsrc, (const char *)packed_t, woff, lds, scr_wave, Breg, out, carry, sm, sl, rec, 0, 256 * 1 + 224, tid, lane);
 #undef NEXT_STEP
     {   // the last tile of the last step: nothing left to hide it behind
         f32x16 a = out[7];
