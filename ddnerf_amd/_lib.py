@@ -88,7 +88,7 @@ _SIGS = {
     "ddnerf_mlp_f32_forward_train_recp": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_mlp_f32_backward_data_recp": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_mlp_f32_sign_bytes": (C.c_size_t, [C.c_long]),
-    "ddnerf_mlp_f32_forward_train_recf": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_mlp_f32_forward_train_recf": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_long, C.c_long, c_fp]),
     "ddnerf_mlp_f32_backward_data_recf": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_ray_bundle": (C.c_int, [C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "ddnerf_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),

@@ -403,16 +403,24 @@ DDN_EXPORT size_t ddnerf_mlp_f32_sign_bytes(long ld) { return ld > 0 ? (size_t)(
 #define F32_SIGNS_PARAM , void *__restrict__ signs
 #define F32_SIGNS_CPARAM , const void *__restrict__ signs
 #define F32_SIGNS_ARG , signs
+// ... and, optionally, the view-direction columns from a per-ray table [n,32] (ddnerf_encode_rays) instead of columns 96..127 of the sample's
+// own row, as the inference kernel takes them (mlp_f32_fwd.inc, F32Dirs); the record of the input columns is the same either way
+#define F32_DIRS_KPARAM , F32Dirs ds
+#define F32_DIRS_KARG , ds
+#define F32_DIRS_PARAM , const float *dirs, int S
 #else
 #define F32_SIGNS_PARAM
 #define F32_SIGNS_CPARAM
 #define F32_SIGNS_ARG
+#define F32_DIRS_KPARAM
+#define F32_DIRS_KARG
+#define F32_DIRS_PARAM
 #endif
 template <bool DEPTH>
 __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_fwd_train_kernel)(const float *__restrict__ feat,
                                                                    const float *__restrict__ packed, FwdOffsets fo,
                                                                    float *__restrict__ raw, float *__restrict__ acts,
-                                                                   long M, long ld F32_SIGNS_PARAM) {
+                                                                   long M, long ld F32_SIGNS_PARAM F32_DIRS_KPARAM) {
     __shared__ __attribute__((aligned(16))) float lds[F32_FWD_LDS_FLOATS];
     Recorder rec;
     rec.acts = acts;
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void F32_NAME(mlp_f32_fwd_train_kernel)(con
     rec.signs = (const char *)signs;
 #endif
     // (tiles past M inside ld -- ld is a multiple of 128 -- are recorded too, from the last sample's features: their deltas are zero)
-    mlp_f32_forward_tiles<DEPTH>(lds, feat, packed, 4u * (unsigned)fo.bias_off[0], raw, M, rec);
+    mlp_f32_forward_tiles<DEPTH>(lds, feat, packed, 4u * (unsigned)fo.bias_off[0], raw, M, rec F32_DIRS_KARG);
 #if F32_SIGNS
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");   // the scalar stores leave the scalar data cache
 #endif
@@ -439,10 +447,16 @@ static FwdOffsets fwd_offsets() {
 }
 
 DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_forward_train)(const float *feat, const float *packed, int depth_head, float *raw,
-                                            float *acts F32_SIGNS_PARAM, long M, long ld, ddnerf_stream_t stream) {
+                                            float *acts F32_SIGNS_PARAM F32_DIRS_PARAM, long M, long ld, ddnerf_stream_t stream) {
     DDN_REQUIRE(feat && packed && raw && acts, DDNERF_E_ARG);
 #if defined(F32_REC) && F32_REC == 3
     DDN_REQUIRE(signs && ddn_aligned(signs, 128), DDNERF_E_ARG);
+    F32Dirs ds = {nullptr, 0u};
+    if (dirs) {   // (n S^2 < 2^32: the ray of a sample comes from a 32-bit multiply-high, as in ddnerf_mlp_f32_forward_rays)
+        DDN_REQUIRE(S > 1 && M % S == 0 && ddn_aligned(dirs, 16), DDNERF_E_ARG);
+        DDN_REQUIRE((unsigned long long)M * (unsigned long long)S < (1ull << 32), DDNERF_E_RANGE);
+        ds = F32Dirs{dirs, (unsigned)(((1ull << 32) + (unsigned)S - 1) / (unsigned)S)};
+    }
 #endif
     DDN_REQUIRE(M > 0, DDNERF_E_ARG);
     DDN_REQUIRE(ld >= M && ld % 128 == 0, DDNERF_E_RANGE);
@@ -455,10 +469,10 @@ DDN_EXPORT int F32_NAME(ddnerf_mlp_f32_forward_train)(const float *feat, const f
     dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));   // persistent (mlp_f32_fwd.inc)
     if (depth_head)
         hipLaunchKernelGGL(F32_NAME(mlp_f32_fwd_train_kernel)<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
-                           acts, M, ld F32_SIGNS_ARG);
+                           acts, M, ld F32_SIGNS_ARG F32_DIRS_KARG);
     else
         hipLaunchKernelGGL(F32_NAME(mlp_f32_fwd_train_kernel)<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, packed, fo, raw,
-                           acts, M, ld F32_SIGNS_ARG);
+                           acts, M, ld F32_SIGNS_ARG F32_DIRS_KARG);
     return ddn_launch_status();
 }
 

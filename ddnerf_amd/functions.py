@@ -77,12 +77,14 @@ class _MLPFunction(torch.autograd.Function):
     ops.WGRAD_MODE."""
 
     @staticmethod
-    def forward(ctx, feat, net, *params):
+    def forward(ctx, feat, net, dirs, S, *params):
         if net.mlp_dtype in ("bf16", "fp16"):
             raise NotImplementedError("training runs on the fp32 / x3 MLP kernels; the plain bf16 / fp16 kernels are inference-only")
         ctx.x3 = net.mlp_dtype == "x3"
         ctx.x3e = ctx.x3 and x3_wgrad_exact()
         ctx.rec = False
+        if dirs is not None and ctx.x3:
+            raise NotImplementedError("per-ray view directions in training: the fp32 tier's values-record kernels only (mlp_rays_trainable)")
         if ctx.x3e:
             raw, acts, bits = ops.mlp_x3e_forward_train(feat, _cached_pack(net, "x3e", ops.mlp_x3e_pack), net.depth_head)
             ctx.save_for_backward(feat, acts, bits)
@@ -96,8 +98,10 @@ class _MLPFunction(torch.autograd.Function):
             # form); "pairs": bf16 row-pair records, one MFMA per product (an opt-in speed mode: bf16-rounded operands); "f32": fp32
             # matrices and the fp32-MFMA kernel
             ctx.rec = {"x3": "values", "x3words": "hilo", "pairs": "pairs"}.get(ops.WGRAD_MODE, False)
+            if dirs is not None and ctx.rec != "values":
+                raise NotImplementedError("per-ray view directions in training: the fp32 tier's values-record kernels only (mlp_rays_trainable)")
             if ctx.rec == "values":
-                raw, acts, signs = ops.mlp_f32_forward_train(feat, _packed_weights(net), net.depth_head, rec=ctx.rec)
+                raw, acts, signs = ops.mlp_f32_forward_train(feat, _packed_weights(net), net.depth_head, rec=ctx.rec, dirs=dirs, S=S)
                 ctx.save_for_backward(feat, acts, signs)
             else:
                 raw, acts = ops.mlp_f32_forward_train(feat, _packed_weights(net), net.depth_head, rec=ctx.rec)
@@ -128,7 +132,12 @@ class _MLPFunction(torch.autograd.Function):
         reducer = getattr(net, "grad_reducer", None)
         if reducer is not None:
             reducer.on_flat_grad_ready(net, flat_g)
-        return (None, None) + tuple(views)
+        return (None, None, None, None) + tuple(views)
+
+
+def mlp_rays_trainable(net):
+    """training with the view-direction columns from a per-ray table: the fp32 tier's default (values-record) kernels take them"""
+    return net.mlp_dtype == "fp32" and ops.WGRAD_MODE == "x3"
 
 
 def needs_grad(net):
@@ -141,7 +150,10 @@ def encode_mlp_bf16(table, t_vals, net):
 
 
 def mlp_rays(feat, dirs, S, net):
-    """inference on the fp32 / x3 kernels with the view-direction columns from the per-ray table `dirs` [n,32] (ops.encode_rays)"""
+    """the fp32 / x3 kernels with the view-direction columns from the per-ray table `dirs` [n,32] (ops.encode_rays): inference, or -- the
+    fp32 tier's values-record kernels -- a training forward"""
+    if needs_grad(net):
+        return _MLPFunction.apply(feat, net, dirs, int(S), *net.parameters())
     fwd = {"fp32": ops.mlp_f32_forward_rays, "x3": ops.mlp_x3_forward_rays}[net.mlp_dtype]
     return fwd(feat, dirs, S, _packed_weights(net), net.depth_head)
 
@@ -149,7 +161,7 @@ def mlp_rays(feat, dirs, S, net):
 def mlp(feat, net):
     """feat [M,128] (fp32, or k-ordered bf16 / fp16 for the bf16 / fp16 kernels) -> raw [M,4|6]"""
     if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
-        return _MLPFunction.apply(feat, net, *net.parameters())
+        return _MLPFunction.apply(feat, net, None, 0, *net.parameters())
     return _forward_kernel(feat, net)
 
 

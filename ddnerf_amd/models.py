@@ -56,7 +56,7 @@ FUSE_RENDER = _os.environ.get("DDNERF_FUSE_RENDER", "1") != "0"
 # bf16 and fp16 tiers: run_network (models/models.py:117-142) as ONE launch, the encoder inside the MLP kernel (ops.encode_mlp_bf16_forward;
 # bit-identical to encode + MLP).  "all" both passes, "fine" the fine pass only, "0" never.
 FUSE_ENCODER = _os.environ.get("DDNERF_FUSE_ENCODER", "all")
-# fp32 / x3 tiers, inference: the view-direction columns once per RAY (ops.encode_rays + mlp_*_forward_rays), as the reference computes them
+# fp32 / x3 tiers, inference -- and the fp32 tier's training forward --: the view-direction columns once per RAY (ops.encode_rays + mlp_*_forward_rays), as the reference computes them
 # (models/models.py:128-133), instead of once per sample in the feature rows; same outputs.  DDNERF_RAY_DIRS=0: per-sample columns.
 RAY_DIRS = _os.environ.get("DDNERF_RAY_DIRS", "1") != "0"
 KERNEL_NOISE = _os.environ.get("DDNERF_KERNEL_NOISE", "1") != "0"   # (0: the compositing noise comes from a torch generator launch again)
@@ -282,7 +282,8 @@ class GeneralMipNerfModel(torch.nn.Module):
             self._ray_table = (ray_batch, table)
             raw = F.encode_mlp_bf16(table, t_vals, network)
             return raw.reshape(n, S, raw.shape[-1])
-        ray_dirs = RAY_DIRS and kind == "fp32" and network.mlp_dtype in ("fp32", "x3") and ops.mlp_rays_supported(S, n * S) and not F.needs_grad(network)
+        ray_dirs = (RAY_DIRS and kind == "fp32" and network.mlp_dtype in ("fp32", "x3") and ops.mlp_rays_supported(S, n * S)
+                    and (not F.needs_grad(network) or F.mlp_rays_trainable(network)))   # (training: the fp32 tier's values-record kernels, round 5)
         dirs = None
         if first:
             # the coarse pass of a one-chunk batch: this launch also fills ray_batch and t_vals (get_rays_batches handed them out empty)

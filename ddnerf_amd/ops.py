@@ -686,12 +686,13 @@ def mlp_f32_pack_t(params_flat, depth_head):
 _REC_SUFFIX = {False: "", None: "", True: "_rec", "hilo": "_rec", "pairs": "_recp", "values": "_recf"}
 
 
-def mlp_f32_forward_train(feat, packed, depth_head, rec=False):
+def mlp_f32_forward_train(feat, packed, depth_head, rec=False, dirs=None, S=0):
     """forward + recorded activations: returns raw [M,4|6], acts [2560, ld] (fp32, transposed: row = feature).  rec=True / "hilo": a
     record of blocked hi/lo words instead -- x3_unsplit reads it back -- for the packed-operand weight-gradient kernel; rec="pairs": a
     record of bf16 row pairs ([1280, ld] words, x3_unpair reads it back) for the one-MFMA weight-gradient kernel; rec="values": the blocked
     layout of the hi/lo words holding the fp32 values themselves (x3_unblock reads it back), for ddnerf_mlp_x3_wgrad_blocked -- and a THIRD
-    result, the sign record (uint8 [ddnerf_mlp_f32_sign_bytes(ld)]) mlp_f32_backward_data(rec="values") takes its ReLU masks from"""
+    result, the sign record (uint8 [ddnerf_mlp_f32_sign_bytes(ld)]) mlp_f32_backward_data(rec="values") takes its ReLU masks from; with
+    `dirs` [M / S, 32] (encode_rays) that build takes the view-direction columns from the per-ray table instead of columns 96..127 of `feat`"""
     fn = "ddnerf_mlp_f32_forward_train" + _REC_SUFFIX[rec]
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
@@ -699,7 +700,9 @@ def mlp_f32_forward_train(feat, packed, depth_head, rec=False):
     raw = torch.empty((M, 6 if depth_head else 4), dtype=torch.float32, device=feat.device)
     acts = _record((ACT_ROWS // 2 if rec == "pairs" else ACT_ROWS, ld), torch.float32, feat.device)
     signs = _record((_lib.lib().ddnerf_mlp_f32_sign_bytes(ld),), torch.uint8, feat.device) if rec == "values" else None
-    extra = (_ptr(signs),) if rec == "values" else ()
+    if dirs is not None and rec != "values":
+        raise _lib.DDNerfHipError("mlp_f32_forward_train: per-ray view directions need rec='values'")
+    extra = (_ptr(signs), _ptr(_f32c(dirs, "dirs")) if dirs is not None else None, int(S)) if rec == "values" else ()
 
     def launch():
         _lib.check(getattr(_lib.lib(), fn)(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts), *extra, M, ld, _stream()), fn)

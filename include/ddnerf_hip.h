@@ -389,10 +389,12 @@ int ddnerf_mlp_f32_backward_data_recp(const float *g_raw, const float *packed_t,
  * `signs`: the SIGN record the forward also writes and the backward reads for its ReLU masks instead of the activations themselves (1 bit
  * instead of 32 per value): ddnerf_mlp_f32_sign_bytes(ld) bytes, 128-byte aligned; per 128-sample tile 32 KiB = [32-row block of
  * layers_xyz.0-7's outputs, 64][wave = 32 samples, 4][accumulator register r, 16] 64-bit lane masks (bit 32 h + j: row 32 block +
- * (r & 3) + 8 (r >> 2) + 4 h, sample 32 wave + j, is > 0), written by scalar stores and read by scalar loads. */
+ * (r & 3) + 8 (r >> 2) + 4 h, sample 32 wave + j, is > 0), written by scalar stores and read by scalar loads.
+ * `dirs` / `S` (forward; dirs may be NULL): the view-direction columns from the per-ray table [M / S, 32] of ddnerf_encode_rays instead of
+ * columns 96..127 of the rows, as in ddnerf_mlp_f32_forward_rays (same outputs and records; M S < 2^32). */
 size_t ddnerf_mlp_f32_sign_bytes(long ld);
 int ddnerf_mlp_f32_forward_train_recf(const float *feat, const float *packed, int depth_head, float *raw, float *acts, void *signs,
-                                  long M, long ld, ddnerf_stream_t stream);
+                                  const float *dirs, int S, long M, long ld, ddnerf_stream_t stream);
 int ddnerf_mlp_f32_backward_data_recf(const float *g_raw, const float *packed_t, const float *acts, const void *signs, int depth_head,
                                   float *deltas, long M, long ld, ddnerf_stream_t stream);
 size_t ddnerf_mlp_f32_wgrad_workspace_floats(long M);

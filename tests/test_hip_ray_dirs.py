@@ -89,3 +89,52 @@ def test_run_iter_is_the_same_with_per_ray_and_per_sample_view_directions(name, 
         for lvl in ref:
             for k in ("rgb", "depth", "acc", "disp", "weights"):
                 assert torch.equal(torch.nan_to_num(out[lvl][k]), torch.nan_to_num(ref[lvl][k])), (chunk, lvl, k)
+
+
+@pytest.mark.parametrize("depth", [False, True])
+def test_training_forward_takes_per_ray_view_directions(ops, depth):
+    """(round 5) the fp32 tier's values-record training forward with the view-direction columns from the per-ray table: raw, the activation
+    record (the transposed input columns included: the weight gradients of layers_dir contract them) and the sign record BIT FOR BIT those of
+    the forward on full rows."""
+    flat = _flat(depth, 13, 20.0)
+    packed = ops.mlp_f32_pack(flat, depth)
+    for kind, n, S in (("blender", 512, 128), ("llff", 41, 33), ("blender", 3, 7)):
+        _, rays, t = _inputs(ops, kind, n, S, n + 5 * S)
+        raw0, acts0, signs0 = ops.mlp_f32_forward_train(ops.encode(rays, t, kind="fp32"), packed, depth, rec="values")
+        feat, dirs = ops.encode_rays(rays, t)
+        feat.view(n, S, 128)[..., 96:] = float("nan")
+        raw1, acts1, signs1 = ops.mlp_f32_forward_train(feat, packed, depth, rec="values", dirs=dirs, S=S)
+        torch.cuda.synchronize()
+        M = n * S
+        assert torch.equal(raw1, raw0)
+        a0, a1 = ops.x3_unblock(acts0)[:2555, :M], ops.x3_unblock(acts1)[:2555, :M]
+        assert torch.equal(a1, a0) and not torch.isnan(a1).any()
+        assert torch.equal(signs1, signs0)
+
+
+def test_training_step_is_the_same_with_per_ray_and_per_sample_view_directions(monkeypatch):
+    """loss and every parameter gradient of one run_iter training pass, RAY_DIRS on against off: bit-identical"""
+    from _cases import load_fullsize
+    from ddnerf_amd import models as M
+    from test_hip_run_iter import build_model
+
+    c = load_fullsize("fullsize_cfg2_dd_blender_4096_64x128")
+    ro, rd, rad, tgt = (torch.from_numpy(x).cuda()[:1024] for x in synthetic.make_rays(c["kind"], c["n"], 1))
+
+    def run(on):
+        monkeypatch.setattr(M, "RAY_DIRS", on)
+        model = build_model(c)
+        model.rng = M.TorchRng()            # (the fixture is a validation case: its replay list is empty; training draws)
+        torch.manual_seed(0)
+        model.train()
+        out = model.run_iter(ro, rd, rad, mode="train", rgb_target=tgt)
+        loss = sum(((out[j]["rgb"] - tgt) ** 2).mean() for j in range(2)) + 0.01 * out[1]["dp_loss"].mean()
+        loss.backward()
+        return loss.detach(), [p.grad.clone() for net in (model.coarse, model.fine) for p in net.parameters()], model
+
+    l0, g0, _ = run(False)
+    l1, g1, model = run(True)
+    assert getattr(model.fine, "_fwd_calls", 0) >= 1
+    assert torch.equal(l0, l1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)

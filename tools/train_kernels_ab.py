@@ -50,7 +50,7 @@ def run(names):
             assert lib.ddnerf_mlp_f32_pack(P(params.data_ptr()), 1, P(packed.data_ptr()), None) == 0
             assert lib.ddnerf_mlp_f32_pack_t(P(params.data_ptr()), 1, P(packed_t.data_ptr()), None) == 0
             go = lambda: lib.ddnerf_mlp_f32_forward_train_recf(P(feat.data_ptr()), P(packed.data_ptr()), 1, P(raw.data_ptr()), P(acts.data_ptr()),
-                                                              P(signs.data_ptr()), L(M), L(M), None)
+                                                              P(signs.data_ptr()), None, 0, L(M), L(M), None)
             gob = lambda: lib.ddnerf_mlp_f32_backward_data_recf(P(graw.data_ptr()), P(packed_t.data_ptr()), P(acts.data_ptr()), P(signs.data_ptr()), 1,
                                                                P(deltas.data_ptr()), L(M), L(M), None)
             for fn, res in ((go, fw), (gob, bw)):
