@@ -64,6 +64,11 @@ def test_render_line_has_the_contract_fields():
     assert br["encoder_in_kernel"] is True and "g2e" in br["kernel"] and "encoder inside" in clk["kernel"]
     um = br["unfused_mlp_launch"]
     assert 0.3 < um["frac"] < 1.0 and um["launch_ms"] > 0 and um["encode_launch_ms"] > 0 and um["launch_ms"] + um["encode_launch_ms"] > br["launch_ms"]
+    # ... the fp16 tier its twin; the fp32 training step the values records with the 1-bit ReLU masks (the word records are an A/B mode)
+    assert d["fp16_tier"]["roofline"]["encoder_in_kernel"] is True and "f16g2e" in d["fp16_tier"]["roofline"]["kernel"]
+    tr = tt["fp32"]["roofline"]
+    assert tr["wgrad_mode"] == "x3" and "fp32 values" in tr["records"] and "scalar memory" in tr["records"], tr
+    assert tt["fp32_pairs"]["roofline"]["wgrad_mode"] == "pairs" and tt["x3"]["roofline"]["wgrad_mode"] is None
     for tier in ("fp32", "fp16", "bf16"):
         im = d["image"][tier]
         assert im["size"] == "800x800" and im["chunks"] == 40 and im["rays_per_s"] > 0 and 0.9 <= im["image_over_chunk_rate"] <= 1.1, (tier, im)
