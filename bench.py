@@ -630,14 +630,16 @@ def measured_traffic(args):
     in the file) and at this launch size; otherwise null."""
     import glob
 
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic_%s.json" % args.mlp)))
+    # (the 16-bit tiers' fine launch is the fused encoder + MLP kernel unless DDNERF_FUSE_ENCODER=0: the two-launch form has its own file)
+    tag = args.mlp + ("_unfused" if args.mlp in ("bf16", "fp16") and os.environ.get("DDNERF_FUSE_ENCODER", "all") == "0" else "")
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic_%s.json" % tag)))
     if not (found and (args.rays, args.fine) == (4096, 128)):
         return None, None
     tf = found[-1]
     d = json.load(open(tf))
     if d.get("kernel_source_md5") != kernel_source_digest(args.mlp):
         return None, None
-    return d.get("fine_mlp_%s_fwd_hbm_bytes_per_launch" % args.mlp), os.path.relpath(tf, ROOT)
+    return d.get("fine_mlp_%s_fwd_hbm_bytes_per_launch" % args.mlp, d.get("fine_mlp_%su_fwd_hbm_bytes_per_launch" % args.mlp)), os.path.relpath(tf, ROOT)
 
 
 def main(argv=None):
