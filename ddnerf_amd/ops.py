@@ -1029,8 +1029,41 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
         if net.depth_head:
             job(ROW_X + 4, 2, ROW_DIR, 128, 128, gv["fc_mu_sigma.weight"], 128, 0, gv["fc_mu_sigma.bias"])
     if pair:
-        for st, _ in lanes:  # the caller's stream continues behind both lanes (which also orders the frees of acts / deltas / ws)
+        events = []
+        for st, _ in lanes:
             done = torch.cuda.Event()
             done.record(st)
-            main.wait_event(done)
+            events.append(done)
+        again = any(entry[1] is net for entry in _DEFERRED)
+        if again:   # a second backward node of the SAME network (one shared MLP): autograd ADDS its gradients to the first node's on the
+            join_deferred(net)   # caller's stream right behind this call -- both must be complete
+        if DEFER_JOIN and not again:
+            # the caller promised that nothing reads these gradients before join_deferred(): its stream goes on (the other network's
+            # backward chain) while the lanes finish -- the tail of a network's jobs (heads, reductions, copies) fills a fraction of the
+            # chip.  Everything the lanes still read or write stays referenced until the join (the allocator must not hand it out).
+            _DEFERRED.append((events, net, (acts, deltas, flat_g, lanes, locals().get("t1"), locals().get("b1"), locals().get("t2"), locals().get("b2"))))
+        else:
+            for done in events:  # the caller's stream continues behind both lanes (which also orders the frees of acts / deltas / ws)
+                main.wait_event(done)
     return flat_g, views
+
+
+# mlp_f32_weight_grads leaves its two lanes unjoined while this is set; join_deferred() joins them (train_step.TrainStepper: around
+# loss.backward(), when no gradient reducer wants the buffers earlier)
+DEFER_JOIN = False
+_DEFERRED = []
+
+
+def join_deferred(net=None):
+    """the current stream waits for the weight-gradient lanes left unjoined under DEFER_JOIN -- all of them, or those of `net` --; their
+    operands are released"""
+    if _DEFERRED:
+        main = torch.cuda.current_stream()
+        keep = []
+        for entry in _DEFERRED:
+            if net is None or entry[1] is net:
+                for e in entry[0]:
+                    main.wait_event(e)
+            else:
+                keep.append(entry)
+        _DEFERRED[:] = keep

@@ -13,12 +13,15 @@ from . import schedules
 
 # the loss of train_model.py:156-172 as one launch + one for its gradient (ddnerf_train_loss_*); DDNERF_FUSED_LOSS=0: the torch op chain
 FUSED_LOSS = os.environ.get("DDNERF_FUSED_LOSS", "1") != "0"
+# the weight-gradient lanes of both networks joined once, behind loss.backward() (DDNERF_DEFER_WGRAD_JOIN=0: at the end of each network's node)
+DEFER_WGRAD_JOIN = os.environ.get("DDNERF_DEFER_WGRAD_JOIN", "1") != "0"
 
 
 class TrainStepper:
     def __init__(self, model, cfg, dist=False, optimizers=None, single_rank_collectives=False):
         self.model, self.cfg = model, cfg
         self.dd = cfg.nerf.type == "DDNerfModel"
+        self.own_optims = optimizers is None   # (then optims[k] is known to be network k's: coarse, fine)
         if optimizers is None:  # train_model.py:84-98: one optimiser per network, lr set per step
             opt = getattr(torch.optim, cfg.optimizer.type)
             # (same update rule; on the GPU torch's fused implementation is ONE kernel per optimiser instead of six multi-tensor
@@ -59,11 +62,30 @@ class TrainStepper:
                 dp = out[1]["dp_loss"].mean()                                                      # :163-167
                 loss = loss + cfg.train_params.dp_coeficient * dp
                 losses.append(dp)
-        loss.backward()
+        # (single GPU: the weight-gradient lanes of a network are joined behind the whole backward pass, not at the end of that network's
+        # node: the other network's backward chain runs beside their tail.  With gradient buckets the reducer wants each buffer at once.)
+        from . import ops
+        # (one shared MLP, GeneralMipNerfModel: its two backward nodes' gradients are ADDED on this stream as soon as the second returns)
+        ops.DEFER_JOIN = self.buckets is None and DEFER_WGRAD_JOIN and len(self.optims) > 1
+        try:
+            loss.backward()
+        finally:
+            ops.DEFER_JOIN = False
+            if not self.own_optims:
+                ops.join_deferred()
         if self.buckets is not None:
             self.buckets.finish()
-        for o in self.optims:
-            o.step()
-            o.zero_grad()
+        if self.own_optims:
+            # (the fine network's backward ran first: its lanes are done first, and its optimiser step runs beside the coarse lanes' tail)
+            nets = [model.coarse] + ([model.fine] if len(self.optims) > 1 else [])
+            for net, o in reversed(list(zip(nets, self.optims))):
+                ops.join_deferred(net)
+                o.step()
+                o.zero_grad()
+            ops.join_deferred()
+        else:
+            for o in self.optims:
+                o.step()
+                o.zero_grad()
         self.iter += 1
         return loss.detach(), [l.detach() for l in losses], out

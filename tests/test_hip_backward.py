@@ -491,3 +491,68 @@ def test_fused_training_loss_equals_the_torch_op_chain(n, n_dp, levels):
     for got, w in zip((rgb0.grad, rgb1.grad, dp.grad if n_dp else None), want):
         if w is not None:
             assert torch.allclose(got, w, rtol=2e-6, atol=1e-12), float((got - w).abs().max())
+
+
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "x3"])
+def test_deferred_weight_gradient_join_changes_nothing(mlp_dtype, monkeypatch):
+    """TrainStepper leaves the two weight-gradient lanes of each network unjoined until the whole backward pass is queued (round 5: the
+    other network's backward chain runs beside their tail).  Four optimiser steps at BASELINE size -- where the lanes really are still
+    busy when the backward returns -- with the join deferred and with it at the end of each network's node: every parameter bit-identical."""
+    from _cases import load_fullsize
+    from ddnerf_amd import models as M
+    from ddnerf_amd import synthetic as syn
+    from ddnerf_amd import train_step
+    from test_hip_run_iter import build_model
+
+    c = load_fullsize("fullsize_cfg2_dd_blender_4096_64x128")
+    ro, rd, rad, tgt = (torch.from_numpy(x).cuda() for x in syn.make_rays(c["kind"], c["n"], 1))
+
+    def run(defer):
+        monkeypatch.setattr(train_step, "DEFER_WGRAD_JOIN", defer)
+        model = build_model(c)
+        model.cfg.nerf["mlp_dtype"] = mlp_dtype
+        model._set_mlp_dtype()
+        model.rng = M.TorchRng()
+        torch.manual_seed(0)
+        stepper = train_step.TrainStepper(model, model.cfg)
+        for _ in range(4):
+            loss, _, _ = stepper.step(ro, rd, rad, tgt)
+        torch.cuda.synchronize()
+        return loss, [p.detach().clone() for net in (model.coarse, model.fine) for p in net.parameters()]
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert torch.equal(l0, l1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
+def test_deferred_join_with_one_shared_network(ops):
+    """GeneralMipNerfModel evaluates ONE network at both levels: its two backward nodes' gradients are added on the caller's stream as soon as
+    the second node returns, so the lanes of the first must be joined there, deferral or not (ops.mlp_f32_weight_grads, `again`)."""
+    from _cases import load_fullsize
+    from ddnerf_amd import models as M
+    from ddnerf_amd import synthetic as syn
+    from test_hip_run_iter import build_model
+
+    c = load_fullsize("fullsize_cfg5_mip_blender_4096_64x128")
+    ro, rd, rad, tgt = (torch.from_numpy(x).cuda() for x in syn.make_rays(c["kind"], c["n"], 1))
+
+    def run(defer):
+        model = build_model(c)
+        model.rng = M.TorchRng()
+        torch.manual_seed(0)
+        model.train()
+        out = model.run_iter(ro, rd, rad, mode="train", rgb_target=tgt)
+        loss = sum(((out[j]["rgb"] - tgt) ** 2).mean() for j in range(2))
+        ops.DEFER_JOIN = defer
+        try:
+            loss.backward()
+        finally:
+            ops.DEFER_JOIN = False
+            ops.join_deferred()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in model.coarse.parameters()]
+
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)
