@@ -69,10 +69,13 @@ class TrainStepper:
         ops.DEFER_JOIN = self.buckets is None and DEFER_WGRAD_JOIN and len(self.optims) > 1
         try:
             loss.backward()
-        finally:
+        except BaseException:
             ops.DEFER_JOIN = False
-            if not self.own_optims:
-                ops.join_deferred()
+            ops.join_deferred()      # (nothing stays referenced behind a failed step)
+            raise
+        ops.DEFER_JOIN = False
+        if not self.own_optims:
+            ops.join_deferred()
         if self.buckets is not None:
             self.buckets.finish()
         if self.own_optims:
