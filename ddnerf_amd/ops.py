@@ -871,6 +871,7 @@ _RECORD_MODES = ("x3p", "x3h", "x3b")
 
 
 WGRAD_PAIRED = os.environ.get("DDNERF_WGRAD_PAIRED", "1") != "0"
+WGRAD_PLAN = os.environ.get("DDNERF_WGRAD_PLAN", "1") != "0"     # (0: the jobs dealt to the two lanes round-robin in layer order, as before round 5)
 _SIDE = {}
 
 
@@ -968,31 +969,44 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
     else:
         lanes = [(main, torch.empty(nws, dtype=torch.float32, device=acts.device))]
     turn = [0]
+    # Two lanes: which job runs on which, and in what order, is PLANNED (round 5) instead of dealt round-robin in layer order.  The jobs'
+    # times at BASELINE size (paired, fine pass): the skip layer 395 us, the 256 x 256 jobs 305 - 315, layer 0 (96 columns) 258, the two small
+    # ones (heads 6 x 128, the dir layer's 32 view columns) 110 - 115 at a fraction of the chip's bandwidth.  Longest-first assignment balances the
+    # lanes within 30 us (round-robin: 142), and the small jobs sit at the FRONT of one lane and at the END of the other, beside a big job
+    # of the other lane each, instead of both at the end beside each other.
+    planned = pair and records and WGRAD_PLAN
+    pending, lane_of = {}, {}
+    plan = (("dir32", "l5", "l1", "l3", "l7", "l0"), ("t1", "l2", "l4", "l6", "feat", "t2"))
 
-    def job(*a):
-        st, ws = lanes[turn[0] % len(lanes)]
-        turn[0] += 1
-        with torch.cuda.stream(st):
-            mlp_f32_wgrad_job(deltas, a[0], a[1], acts, a[2], a[3], a[4], M, a[5], a[6], a[7], a[8], ws, mode=mode,
-                              max_wg=128 if pair else 0)
+    def on_lane(name, fn):
+        """fn(stream, workspace) launches job `name`: now, on the next lane in turn -- or, planned, when its lane's turn comes"""
+        if planned:
+            pending[name] = fn
+        else:
+            st, ws = lanes[turn[0] % len(lanes)]
+            turn[0] += 1
+            lane_of[name] = st
+            with torch.cuda.stream(st):
+                fn(st, ws)
+
+    def job(name, *a):
+        on_lane(name, lambda st, ws: mlp_f32_wgrad_job(deltas, a[0], a[1], acts, a[2], a[3], a[4], M, a[5], a[6], a[7], a[8], ws, mode=mode,
+                                                       max_wg=128 if pair else 0))
 
     for l in range(8):
         w, b = gv["layers_xyz.%d.weight" % l], gv["layers_xyz.%d.bias" % l]
         if l == 0:
-            job(0, 256, ROW_X, 96, 96, w, 96, 0, b)
+            job("l0", 0, 256, ROW_X, 96, 96, w, 96, 0, b)
         elif l == 5 and records:  # cat(xyz, h4) in one pass over the deltas
-            st, ws = lanes[turn[0] % len(lanes)]
-            turn[0] += 1
             skip = _WGRAD_FN[mode] + "_skip"
-            with torch.cuda.stream(st):
-                _lib.check(getattr(_lib.lib(), skip)(_ptr(deltas), 1280, _ptr(acts), ROW_X, 1024, M, deltas.shape[1], _ptr(w),
-                                                     _ptr(b), _ptr(ws), 128 if pair else 0, _stream()), skip)
+            on_lane("l5", lambda st, ws, w=w, b=b: _lib.check(getattr(_lib.lib(), skip)(_ptr(deltas), 1280, _ptr(acts), ROW_X, 1024, M, deltas.shape[1], _ptr(w),
+                                                                                    _ptr(b), _ptr(ws), 128 if pair else 0, _stream()), skip))
         elif l == 5:
-            job(1280, 256, ROW_X, 96, 96, w, 352, 0, b)
-            job(1280, 256, 1024, 256, 256, w, 352, 96, None)
+            job("l5a", 1280, 256, ROW_X, 96, 96, w, 352, 0, b)
+            job("l5b", 1280, 256, 1024, 256, 256, w, 352, 96, None)
         else:
-            job(256 * l, 256, 256 * (l - 1), 256, 256, w, 256, 0, b)
-    job(ROW_FEAT, 256, 256 * 7, 256, 256, gv["fc_feat.weight"], 256, 0, gv["fc_feat.bias"])
+            job("l%d" % l, 256 * l, 256, 256 * (l - 1), 256, 256, w, 256, 0, b)
+    job("feat", ROW_FEAT, 256, 256 * 7, 256, 256, gv["fc_feat.weight"], 256, 0, gv["fc_feat.bias"])
     wd = gv["layers_dir.0.weight"]
     if records:
         # Jobs that contract over the same activations share ONE pass over them (rows ROW_DIR .. ROW_X + 5 of `deltas` are
@@ -1004,11 +1018,18 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
         b1 = torch.empty(160, dtype=torch.float32, device=acts.device)
         t2 = torch.empty((6, 128), dtype=torch.float32, device=acts.device)
         b2 = torch.empty(6, dtype=torch.float32, device=acts.device)
-        job(ROW_DIR, 160, ROW_FEAT, 256, 256, t1, 256, 0, b1)
-        st1 = lanes[(turn[0] - 1) % len(lanes)][0]
-        job(ROW_X, 6, ROW_DIR, 128, 128, t2, 128, 0, b2)
-        st2 = lanes[(turn[0] - 1) % len(lanes)][0]
-        job(ROW_DIR, 128, ROW_X + 96, 32, 27, wd, 283, 256, None)
+        job("t1", ROW_DIR, 160, ROW_FEAT, 256, 256, t1, 256, 0, b1)
+        job("t2", ROW_X, 6, ROW_DIR, 128, 128, t2, 128, 0, b2)
+        job("dir32", ROW_DIR, 128, ROW_X + 96, 32, 27, wd, 283, 256, None)
+        if planned:
+            assert sorted(pending) == sorted(plan[0] + plan[1]), sorted(pending)
+            for i in range(len(plan[0])):          # (enqueued alternately: neither stream waits for the host)
+                for li in (0, 1):
+                    st, ws = lanes[li]
+                    lane_of[plan[li][i]] = st
+                    with torch.cuda.stream(st):
+                        pending[plan[li][i]](st, ws)
+        st1, st2 = lane_of["t1"], lane_of["t2"]
         with torch.cuda.stream(st1):
             wd[:, :256].copy_(t1[:128])
             gv["layers_dir.0.bias"].copy_(b1[:128])
@@ -1021,13 +1042,13 @@ def mlp_f32_weight_grads(net, acts, deltas, M, mode=None):
                 gv["fc_mu_sigma.weight"].copy_(t2[4:6])
                 gv["fc_mu_sigma.bias"].copy_(b2[4:6])
     else:
-        job(ROW_DIR, 128, ROW_FEAT, 256, 256, wd, 283, 0, gv["layers_dir.0.bias"])
-        job(ROW_DIR, 128, ROW_X + 96, 32, 27, wd, 283, 256, None)
+        job("dir", ROW_DIR, 128, ROW_FEAT, 256, 256, wd, 283, 0, gv["layers_dir.0.bias"])
+        job("dir32", ROW_DIR, 128, ROW_X + 96, 32, 27, wd, 283, 256, None)
         # heads: d(raw) rows 0..2 rgb, 3 alpha, 4..5 mu/sigma (deltas rows ROW_X..)
-        job(ROW_X, 3, ROW_DIR, 128, 128, gv["fc_rgb.weight"], 128, 0, gv["fc_rgb.bias"])
-        job(ROW_X + 3, 1, ROW_FEAT, 256, 256, gv["fc_alpha.weight"], 256, 0, gv["fc_alpha.bias"])
+        job("rgb", ROW_X, 3, ROW_DIR, 128, 128, gv["fc_rgb.weight"], 128, 0, gv["fc_rgb.bias"])
+        job("alpha", ROW_X + 3, 1, ROW_FEAT, 256, 256, gv["fc_alpha.weight"], 256, 0, gv["fc_alpha.bias"])
         if net.depth_head:
-            job(ROW_X + 4, 2, ROW_DIR, 128, 128, gv["fc_mu_sigma.weight"], 128, 0, gv["fc_mu_sigma.bias"])
+            job("musigma", ROW_X + 4, 2, ROW_DIR, 128, 128, gv["fc_mu_sigma.weight"], 128, 0, gv["fc_mu_sigma.bias"])
     if pair:
         events = []
         for st, _ in lanes:
