@@ -15,7 +15,7 @@ for cfg in config_ff.yml config_360.yml config_blender_mipnerf.yml; do
 done
 echo benches done
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_fp32 -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-bf16-tier > $O/p_fp32.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_fp32 -o r -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-bf16-tier --no-clock > $O/p_fp32.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_bf16 -o r -- python3 $R/bench.py --mlp bf16 --steps 80 --warmup 2 --no-cpu-baseline --no-clock > $O/p_bf16.log 2>&1
 export DDNERF_FUSE_ENCODER=0
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_bf16u -o r -- python3 $R/bench.py --mlp bf16 --steps 80 --warmup 2 --no-cpu-baseline --no-clock > $O/p_bf16u.log 2>&1
