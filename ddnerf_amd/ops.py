@@ -404,14 +404,25 @@ def _records_slot(dev):
     # a free list: a slot is taken by a launch and handed back by the finish that read it, so any number of chunks may be in flight
     # (run_iter over a whole image enqueues all of them before it reads the first length)
     free = _PINNED.setdefault(str(dev), [])
-    return free.pop() if free else torch.empty(1, dtype=torch.int32).pin_memory()
+    slot = free.pop() if free else torch.empty(1, dtype=torch.int32).pin_memory()
+    slot[0] = -1          # (a host store: the kernel's store of the length, >= 0, is what dd_records_finish waits for)
+    return slot
+
+
+# Round 5: NO event behind the compaction.  The host learns the length by reading the pinned slot until the device's store shows (pinned
+# memory is coherent: a device write becomes visible to the CPU without a flush).  An event recorded in the stream was a barrier packet
+# between the compaction and the fine pass's MLP launch: 11 us of an empty GPU per 0.69-ms chunk (profiles/r05_render_bf16_kernel_stats:
+# the gap in front of every fine launch).  DDNERF_RECORDS_EVENT=1: the event, as before.
+RECORDS_EVENT = os.environ.get("DDNERF_RECORDS_EVENT", "0") == "1"
 
 
 def _records_ticket(outs, host):
-    """the event dd_records_finish waits for, recorded right behind the compaction"""
-    ev = torch.cuda.Event()
-    ev.record()
-    return [outs, host, ev, host]     # (a list: dd_records_finish empties it -- a ticket is good for ONE finish)
+    """what dd_records_finish waits for: the pinned slot itself (or, DDNERF_RECORDS_EVENT=1, an event recorded right behind the compaction)"""
+    ev = None
+    if RECORDS_EVENT:
+        ev = torch.cuda.Event()
+        ev.record()
+    return [outs, host, ev, torch.cuda.current_stream()]     # (a list: dd_records_finish empties it -- a ticket is good for ONE finish)
 
 
 def dd_records_finish(ticket):
@@ -420,9 +431,19 @@ def dd_records_finish(ticket):
     if not ticket:
         # finishing a ticket twice would hand its pinned length slot to the free list twice: two later launches would then share it
         raise _lib.DDNerfHipError("dd_records_finish: this ticket has been finished already")
-    outs, host, ev, _total = ticket
+    outs, host, ev, stream = ticket
     del ticket[:]
-    ev.synchronize()
+    if ev is not None:
+        ev.synchronize()
+    else:
+        import time
+
+        t_end = time.monotonic() + 5.0
+        while int(host[0]) < 0:
+            if time.monotonic() > t_end:      # (a launch that never ran: let the stream report it)
+                stream.synchronize()
+                if int(host[0]) < 0:
+                    raise _lib.DDNerfHipError("dd_records_finish: the compaction kernel did not deliver the records' length")
     k = int(host[0])
     _PINNED.setdefault(str(outs[0].device), []).append(host)
     return tuple(o[:k] for o in outs)
