@@ -215,17 +215,24 @@ class KernelTimer:
     """HIP-event timing of the dominant kernel (the MLP launch of `only` samples: the fine pass) on torch's current stream (the stream
     the C ABI launches on).  An event record is a barrier packet of its own: ~6 us of idle GPU in front of and behind the launch it
     brackets (rocprofv3 kernel trace), so only the launches that are reported carry one -- timing the coarse launch too cost the
-    0.75-ms bf16 step another 12 us."""
+    0.75-ms bf16 step another 12 us.  `every`: time every n-th such launch of the timed region only (the 16-bit tiers, whose whole step
+    is 0.69 ms: a pair of events around EVERY fine launch is 12 us = 1.7 % of the step it is there to measure; around every fourth, 3 us);
+    `seen` counts the launches the timed region contained, `launches_timed` in the line those that carry events."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, every=1):
         self.pairs = []
         self.active = False
         self.only = only
+        self.every = max(1, int(every))
+        self.seen = 0
 
     def __call__(self, M, launch):
         import torch
 
         if not self.active or (self.only is not None and M != self.only):
+            return launch()
+        self.seen += 1
+        if (self.seen - 1) % self.every:
             return launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -699,7 +706,7 @@ def main(argv=None):
     ro, rd, rad, tgt = (torch.from_numpy(x).to(device) for x in synthetic.make_rays(args.ray_kind, args.rays, 1 + rank))
     torch.manual_seed(1234 + rank)
 
-    timer = KernelTimer(only=args.rays * args.fine)
+    timer = KernelTimer(only=args.rays * args.fine, every=4 if (args.mlp in ("bf16", "fp16") and args.mode == "render") else 1)
     ops.MLP_LAUNCH_HOOK = timer
 
     def fence():
@@ -713,6 +720,7 @@ def main(argv=None):
             step()
         fence()
         timer.pairs.clear()
+        timer.seen = 0
         timer.active = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -761,7 +769,7 @@ def main(argv=None):
             roof = {"bound": "mfma", "kernel": "mlp_%s_fwd_kernel<fine> (%d samples/launch)" % (args.mlp, M_fine),
                     "achieved": round(ach, 2), "peak": PEAK[args.mlp], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK[args.mlp], 4), "traffic": traffic, "traffic_source": src, "traffic_measured_in_run": False,
-                    "launch_ms": round(ms, 4), "launches_timed": launches}
+                    "launch_ms": round(ms, 4), "launches_timed": launches, "launches_in_timed_region": timer.seen}
             if args.mlp == "x3":
                 roof["issued_tflops"] = round(3 * ach, 2)
                 roof["frac_issued"] = round(3 * ach / PEAK["x3"], 4)

@@ -62,6 +62,9 @@ def test_render_line_has_the_contract_fields():
     assert 2000 < hc["in_kernel_clock_mhz"] <= 2500 and 0.9 < hc["mfma_share_of_workgroup_cycles"] <= 1.0 and hc["closes_within"] < 0.02, hc
     br = d["bf16_tier"]["roofline"]
     assert br["encoder_in_kernel"] is True and "g2e" in br["kernel"] and "encoder inside" in clk["kernel"]
+    # (a 16-bit tier times every fourth fine launch of its timed region: an event pair is 12 us of idle GPU around the launch it brackets)
+    assert br["launches_in_timed_region"] == d["steps"] and br["launches_timed"] == (d["steps"] + 3) // 4
+    assert d["roofline"]["launches_in_timed_region"] == d["roofline"]["launches_timed"] == d["steps"]
     um = br["unfused_mlp_launch"]
     assert 0.3 < um["frac"] < 1.0 and um["launch_ms"] > 0 and um["encode_launch_ms"] > 0 and um["launch_ms"] + um["encode_launch_ms"] > br["launch_ms"]
     # ... the fp16 tier its twin; the fp32 training step the values records with the 1-bit ReLU masks (the word records are an A/B mode)
