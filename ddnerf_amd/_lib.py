@@ -57,6 +57,7 @@ _SIGS = {
     "ddnerf_mlp_x3_pack": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_x3_forward": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_long, c_fp]),
     "ddnerf_mlp_x3_forward_train": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
+    "ddnerf_mlp_x3_forward_train_rays": (C.c_int, [c_fp, c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_long, C.c_long, c_fp]),
     "ddnerf_mlp_x3_packed_t_bytes": (C.c_size_t, [C.c_int]),
     "ddnerf_mlp_x3_pack_t": (C.c_int, [c_fp, C.c_int, c_fp, c_fp]),
     "ddnerf_mlp_x3_backward_data": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, c_fp, C.c_long, C.c_long, c_fp]),

@@ -46,6 +46,8 @@ SOURCES = {
     # the x3 inference kernel with the view-direction columns from a per-ray table (ddnerf_mlp_x3_forward_rays)
     "mlp_x3_fwd_rays.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     "mlp_x3_fwd_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+    # the x3 training forward with the view-direction columns from a per-ray table (ddnerf_mlp_x3_forward_train_rays)
+    "mlp_x3_fwd_train_rays.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     "mlp_x3_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
     # the x3 training tier's strict mode (DDNERF_X3_WGRAD=exact): the round-2 kernels that record exact hi/lo words
     "mlp_x3e_fwd_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
@@ -57,7 +59,7 @@ SOURCES = {
 # than the wait states nobody pads (csrc/check_asm_hazards.py); a violation fails the build
 CHECKED = {"mlp_bf16.hip": "mlp_bf16_fwd_kernel", "mlp_bf16_g2.hip": "mlp_bf16g2_fwd_kernel", "mlp_bf16_g2e.hip": "mlp_bf16g2e_fwd_kernel", "mlp_f16_g2e.hip": "mlp_f16g2e_fwd_kernel", "mlp_f16.hip": "mlp_f16_fwd_kernel",
            "mlp_f16_g2.hip": "mlp_f16g2_fwd_kernel", "mlp_x3_fwd.hip": "mlp_x3_fwd16_kernel", "mlp_x3_fwd_rays.hip": "mlp_x3_fwd16_rays_kernel",
-           "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel", "mlp_x3_bwd.hip": "mlp_x3_bwd16_kernel",
+           "mlp_x3_fwd_train.hip": "mlp_x3_fwd16_train_kernel", "mlp_x3_fwd_train_rays.hip": "mlp_x3_fwd16_train_rays_kernel", "mlp_x3_bwd.hip": "mlp_x3_bwd16_kernel",
            "mlp_x3e_fwd_train.hip": "mlp_x3e_fwd16_train_kernel", "mlp_x3e_bwd.hip": "mlp_x3e_bwd16_kernel"}
 
 

@@ -83,13 +83,13 @@ class _MLPFunction(torch.autograd.Function):
         ctx.x3 = net.mlp_dtype == "x3"
         ctx.x3e = ctx.x3 and x3_wgrad_exact()
         ctx.rec = False
-        if dirs is not None and ctx.x3:
-            raise NotImplementedError("per-ray view directions in training: the fp32 tier's values-record kernels only (mlp_rays_trainable)")
+        if dirs is not None and ctx.x3e:
+            raise NotImplementedError("per-ray view directions in training: not with DDNERF_X3_WGRAD=exact (mlp_rays_trainable)")
         if ctx.x3e:
             raw, acts, bits = ops.mlp_x3e_forward_train(feat, _cached_pack(net, "x3e", ops.mlp_x3e_pack), net.depth_head)
             ctx.save_for_backward(feat, acts, bits)
         elif ctx.x3:
-            raw, acts, bits = ops.mlp_x3_forward_train(feat, _packed_weights(net), net.depth_head)
+            raw, acts, bits = ops.mlp_x3_forward_train(feat, _packed_weights(net), net.depth_head, dirs=dirs, S=S)
             ctx.save_for_backward(feat, acts, bits)
         else:
             # with the default (bf16x3) weight gradients the exact-fp32 kernels write blocked RECORDS for the record-operand kernel
@@ -136,8 +136,9 @@ class _MLPFunction(torch.autograd.Function):
 
 
 def mlp_rays_trainable(net):
-    """training with the view-direction columns from a per-ray table: the fp32 tier's default (values-record) kernels take them"""
-    return net.mlp_dtype == "fp32" and ops.WGRAD_MODE == "x3"
+    """training with the view-direction columns from a per-ray table: the fp32 tier's default (values-record) kernels and the x3 tier's
+    default (row-pair) kernels take them"""
+    return (net.mlp_dtype == "fp32" and ops.WGRAD_MODE == "x3") or (net.mlp_dtype == "x3" and not x3_wgrad_exact())
 
 
 def needs_grad(net):
@@ -151,7 +152,7 @@ def encode_mlp_bf16(table, t_vals, net):
 
 def mlp_rays(feat, dirs, S, net):
     """the fp32 / x3 kernels with the view-direction columns from the per-ray table `dirs` [n,32] (ops.encode_rays): inference, or -- the
-    fp32 tier's values-record kernels -- a training forward"""
+    tiers' default training kernels, mlp_rays_trainable -- a training forward"""
     if needs_grad(net):
         return _MLPFunction.apply(feat, net, dirs, int(S), *net.parameters())
     fwd = {"fp32": ops.mlp_f32_forward_rays, "x3": ops.mlp_x3_forward_rays}[net.mlp_dtype]

@@ -759,9 +759,10 @@ def mlp_x3_pack_t(params_flat, depth_head):
     return packed
 
 
-def mlp_x3_forward_train(feat, packed, depth_head):
+def mlp_x3_forward_train(feat, packed, depth_head, dirs=None, S=0):
     """x3 forward that records activations: -> raw [M,4|6], acts = a record of bf16 ROW PAIRS, [1280, ld] 32-bit words in a
-    float32-typed tensor (x3_unpair gives the [2560, ld] matrix of the bf16-rounded values), bits [160, ld] uint16 (sign words)"""
+    float32-typed tensor (x3_unpair gives the [2560, ld] matrix of the bf16-rounded values), bits [160, ld] uint16 (sign words);
+    with `dirs` [M / S, 32] (encode_rays) the view-direction columns come from the per-ray table instead of columns 96..127 of `feat`"""
     feat = _f32c(feat, "feat")
     M = feat.shape[0]
     ld = (M + 127) // 128 * 128
@@ -770,6 +771,10 @@ def mlp_x3_forward_train(feat, packed, depth_head):
     bits = _record((ACT_ROWS // 32 * 2, ld), torch.int16, feat.device)
 
     def launch():
+        if dirs is not None:
+            _lib.check(_lib.lib().ddnerf_mlp_x3_forward_train_rays(_ptr(feat), _ptr(_f32c(dirs, "dirs")), int(S), _ptr(packed), int(depth_head), _ptr(raw),
+                                                                   _ptr(acts), _ptr(bits), M, ld, _stream()), "ddnerf_mlp_x3_forward_train_rays")
+            return
         _lib.check(_lib.lib().ddnerf_mlp_x3_forward_train(_ptr(feat), _ptr(packed), int(depth_head), _ptr(raw), _ptr(acts),
                                                           _ptr(bits), M, ld, _stream()), "ddnerf_mlp_x3_forward_train")
 

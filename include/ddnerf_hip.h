@@ -198,6 +198,10 @@ int ddnerf_mlp_x3_forward_rays(const float *feat, const float *dirs, int S, cons
  *   deltas a record like `acts`: every layer's pre-activation gradient, rows as in `acts`; rows 2432.. = d(raw) */
 int ddnerf_mlp_x3_forward_train(const float *feat, const void *packed, int depth_head, float *raw, float *acts, void *bits,
                                 long M, long ld, ddnerf_stream_t stream);
+/* ... with the view-direction columns from the per-ray table `dirs` [M / S, 32] of ddnerf_encode_rays (columns 96..127 of `feat` are not
+ * read), as ddnerf_mlp_x3_forward_rays takes them: the same outputs, record and sign words bit for bit.  M S < 2^32. */
+int ddnerf_mlp_x3_forward_train_rays(const float *feat, const float *dirs, int S, const void *packed, int depth_head, float *raw,
+                                     float *acts, void *bits, long M, long ld, ddnerf_stream_t stream);
 size_t ddnerf_mlp_x3_packed_t_bytes(int depth_head);
 int ddnerf_mlp_x3_pack_t(const float *params, int depth_head, void *packed_t, ddnerf_stream_t stream);
 int ddnerf_mlp_x3_backward_data(const float *g_raw, const void *packed_t, const void *bits, int depth_head, float *deltas,

@@ -112,7 +112,30 @@ def test_training_forward_takes_per_ray_view_directions(ops, depth):
         assert torch.equal(signs1, signs0)
 
 
-def test_training_step_is_the_same_with_per_ray_and_per_sample_view_directions(monkeypatch):
+@pytest.mark.parametrize("depth", [False, True])
+def test_x3_training_forward_takes_per_ray_view_directions(ops, depth):
+    """the x3 tier's training forward likewise: raw, the row-pair record and the sign words bit for bit"""
+    flat = _flat(depth, 14, 20.0)
+    packed = ops.mlp_x3_pack(flat, depth)
+    for kind, n, S in (("blender", 512, 128), ("llff", 41, 33), ("blender", 3, 7)):
+        _, rays, t = _inputs(ops, kind, n, S, n + 7 * S)
+        raw0, acts0, bits0 = ops.mlp_x3_forward_train(ops.encode(rays, t, kind="fp32"), packed, depth)
+        feat, dirs = ops.encode_rays(rays, t)
+        feat.view(n, S, 128)[..., 96:] = float("nan")
+        raw1, acts1, bits1 = ops.mlp_x3_forward_train(feat, packed, depth, dirs=dirs, S=S)
+        torch.cuda.synchronize()
+        M = n * S
+        assert torch.equal(raw1, raw0)
+        a0, a1 = ops.x3_unpair(acts0)[:2555, :M], ops.x3_unpair(acts1)[:2555, :M]
+        assert torch.equal(a1, a0) and not torch.isnan(a1).any()
+        # (sign words of the rows the backward masks: layers_xyz.0-7 = record rows 0..2047 = words 0..127, layers_dir.0 = rows 2304..2431 = words
+        # 144..151; the other words of the buffer are never written)
+        for lo, hi in ((0, 128), (144, 152)):
+            assert torch.equal(bits1[lo:hi, :M], bits0[lo:hi, :M])
+
+
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "x3"])
+def test_training_step_is_the_same_with_per_ray_and_per_sample_view_directions(mlp_dtype, monkeypatch):
     """loss and every parameter gradient of one run_iter training pass, RAY_DIRS on against off: bit-identical"""
     from _cases import load_fullsize
     from ddnerf_amd import models as M
@@ -124,6 +147,8 @@ def test_training_step_is_the_same_with_per_ray_and_per_sample_view_directions(m
     def run(on):
         monkeypatch.setattr(M, "RAY_DIRS", on)
         model = build_model(c)
+        model.cfg.nerf["mlp_dtype"] = mlp_dtype
+        model._set_mlp_dtype()
         model.rng = M.TorchRng()            # (the fixture is a validation case: its replay list is empty; training draws)
         torch.manual_seed(0)
         model.train()
