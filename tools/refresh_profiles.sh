@@ -11,7 +11,7 @@ timeout -k 10 200 python bench.py --mlp fp16 --no-cpu-baseline --no-clock > $O/b
 timeout -k 10 200 python bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_train_fp32.json 2> $O/bench_train_fp32.err
 timeout -k 10 200 python bench.py --mode train --mlp x3 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_train_x3.json 2> $O/bench_train_x3.err
 for cfg in config_ff.yml config_360.yml config_blender_mipnerf.yml; do
-  timeout -k 10 200 python bench.py --config $cfg --no-cpu-baseline --steps 10 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
+  timeout -k 10 200 python bench.py --config $cfg --no-cpu-baseline --steps 40 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
 done
 echo benches done
 cd /tmp; export TMPDIR=/tmp
